@@ -1,0 +1,154 @@
+/*
+ * multical_hip.h -- C ABI of the MI355X (gfx950) backend for the aslam_backend
+ * Gauss-Newton / Levenberg-Marquardt inner loop of zhixy/multical.
+ *
+ * The reference has no C ABI for this path: its plug-in point is the C++ class
+ * aslam::backend::LinearSystemSolver (aslam_optimizer/aslam_backend/include/aslam/backend/
+ * LinearSystemSolver.hpp:16-109), selected through Optimizer2Options::linearSystemSolver
+ * (.../Optimizer2Options.hpp:9-42; Python name `linearSolver`,
+ * aslam_optimizer/aslam_backend_python/src/OptimizerOptions.cpp:37).  Every entry point below
+ * names the reference member function(s) it stands in for; the C++ adapter with the
+ * LinearSystemSolver surface is multical_amd/csrc/hip_linear_system_solver.hpp and the
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host buffer it passes and
+ * the pointers are borrowed for the duration of the call; the context owns all device memory.
+ * All arithmetic is IEEE fp64, indices are 32-bit int.  Every function returns 0 on success and
+ * a negative code on failure unless stated otherwise; mc_last_error() gives the message.  A
+ * context is not thread-safe.  Calls without a `_device` suffix synchronise before returning.
+ */
+#ifndef MULTICAL_HIP_H
+#define MULTICAL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mc_context mc_context;
+
+/* design-variable kinds (reference classes in aslam_backend_expressions / aslam_splines) */
+enum {
+  MC_DV_EUCLIDEAN_POINT = 0,     /* EuclideanPoint        : 3 params, additive            */
+  MC_DV_ROTATION_QUATERNION = 1, /* RotationQuaternion    : 4 params [x y z w], minimal 3 */
+  MC_DV_SCALAR = 2,              /* Scalar                : 1 param                        */
+  MC_DV_EUCLIDEAN_DIRECTION = 3, /* EuclideanDirection    : given as a 3-vector, minimal 2 */
+  MC_DV_SPLINE_COEFF = 4,        /* DesignVariableMappedVector<D> (created by mc_add_spline) */
+  MC_DV_PROJECTION = 5,          /* DesignVariableAdapter<Projection>: 4/5/6 params         */
+  MC_DV_DISTORTION = 6           /* DesignVariableAdapter<Distortion>: 4 params             */
+};
+enum { MC_PROJ_PINHOLE = 0, MC_PROJ_OMNI = 1, MC_PROJ_DS = 2 };
+enum { MC_DIST_NONE = 0, MC_DIST_RADTAN = 1, MC_DIST_EQUI = 2 };
+/* M-estimators, aslam_backend/src/MEstimatorPolicies.cpp:17-129.  param: Huber/Bz k; Cauchy/
+ * Geman-McClure sigma^2; Blake-Zisserman epsilon (= (1-w)/w * exp(-chi2inv(p, df)), computed by
+ * the caller -- the reference evaluates it once in the constructor). */
+enum { MC_MEST_NONE = 0, MC_MEST_HUBER = 1, MC_MEST_CAUCHY = 2, MC_MEST_GEMAN_MCCLURE = 3, MC_MEST_BZ = 4,
+       MC_MEST_BLAKE_ZISSERMAN = 5 };
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* One context drives one GPU (one process per GPU).  device < 0 keeps the current device. */
+mc_context* mc_create(int device);
+void mc_destroy(mc_context* ctx);
+const char* mc_last_error(const mc_context* ctx); /* valid until the next call on ctx; NULL ctx: creation error */
+
+/* ---- problem description (replaces OptimizationProblem::addDesignVariable / addErrorTerm as
+ *      seen by Optimizer2::initialize, aslam_backend/src/Optimizer2.cpp:95-151) ------------- */
+/* Design variables are numbered in call order; that order must be the problem's design-variable
+ * order (incremental_calibration/src/core/OptimizationProblem.cpp:272-292) because it defines the
+ * block indices.  Returns the dv id (>= 0). */
+int mc_add_design_variable(mc_context* ctx, int kind, const double* params, int n_params, int active, double scaling);
+/* BSplinePoseDesignVariable (dim 6, rotation-vector parametrisation) or EuclideanBSplineDesignVariable
+ * (dim 3): adds n_coeff consecutive MC_DV_SPLINE_COEFF design variables.  coeffs is dim x n_coeff,
+ * column major (coefficient i contiguous).  Returns the spline id. */
+int mc_add_spline(mc_context* ctx, int order, int dim, const double* knots, int n_knots, const double* coeffs,
+                  int n_coeff, int active);
+int mc_spline_first_dv(const mc_context* ctx, int spline_id);
+/* Camera geometry whose parameters live in two design variables (active or not). dv_dist < 0 for MC_DIST_NONE. */
+int mc_add_camera(mc_context* ctx, int projection_model, int distortion_model, int dv_projection, int dv_distortion);
+
+/* Error-term batches.  Terms are numbered in call order (row base = running sum of dimensions,
+ * Optimizer2.cpp:130-135).  sqrt_inv_r[k] is the scalar s with sqrtInvR = s*I (Multical uses
+ * isotropic covariances throughout).  All return 0 or a negative error. */
+
+/* SimpleReprojectionError over T_c_b * T_w_b(t + d)^-1 * T_p_w^-1 * p  (sensors_and_targets.py:556-630;
+ * aslam_cv_error_terms/.../SimpleReprojectionError.hpp:43-64; time-offset node
+ * aslam_splines/src/BSplineExpressions.cpp:406-555).  Terms of observation o are
+ * obs_first[o] .. obs_first[o+1]-1.  dv_time_offset < 0: constant time. */
+int mc_add_reprojection_batch(mc_context* ctx, int camera, int pose_spline, int dv_q_c_b, int dv_t_c_b,
+                              int dv_time_offset, int n_obs, const double* obs_time, const int* obs_dv_q_p_w,
+                              const int* obs_dv_t_p_w, const int* obs_first, const double* y /* [n,2] */,
+                              const double* p_target /* [n,3] */, const double* sqrt_inv_r /* [n] */,
+                              double time_padding, int mest_kind, double mest_param);
+/* ReprojectionError with camera design variables over B_{n-1}*..*B_0 * T_target_camera^-1 * p
+ * (kalibr_camera_calibration/CameraCalibrator.py:195-219; ReprojectionError.hpp:50-77;
+ * aslam_cv_backend/.../CameraDesignVariable.hpp:39-54). */
+int mc_add_static_reprojection_batch(mc_context* ctx, int camera, int n_chain, const int* chain_dv_q,
+                                     const int* chain_dv_t, int n_obs, const int* obs_dv_q_t_c,
+                                     const int* obs_dv_t_t_c, const int* obs_first, const double* y,
+                                     const double* p_target, const double* sqrt_inv_r, int mest_kind,
+                                     double mest_param);
+/* kalibr EuclideanError, accelerometer form (sensors_and_targets.py:1133-1179; kalibr/src/EuclideanError.cpp:5-27).
+ * bias_spline < 0: static bias dv_bias.  dv_gravity: EUCLIDEAN_DIRECTION or EUCLIDEAN_POINT. */
+int mc_add_accelerometer_batch(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_gravity,
+                               int dv_q_i_b, int dv_r_b, int n, const double* t, const double* meas /* [n,3] */,
+                               const double* sqrt_inv_r, int mest_kind, double mest_param);
+/* kalibr EuclideanError, gyroscope form (sensors_and_targets.py:1181-1221). */
+int mc_add_gyroscope_batch(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_q_i_b, int n,
+                           const double* t, const double* meas, const double* sqrt_inv_r, int mest_kind,
+                           double mest_param);
+/* Multical LiDAR point-to-plane ScalarError (sensors_and_targets.py:274-305; kalibr/src/ScalarError.cpp:6-31). */
+int mc_add_lidar_batch(mc_context* ctx, int pose_spline, int dv_time_offset, int dv_q_l_b, int dv_t_l_b, int n,
+                       const double* t, const double* dir /* [n,3] unit */, const double* range,
+                       const double* sqrt_inv_r, const int* dv_q_p_w, const int* dv_t_p_w, double time_padding,
+                       int mest_kind, double mest_param);
+/* BSplineMotionError (aslam_splines/include/aslam/backend/implementation/BSplineMotionError.hpp:28-166).  W is dim x dim. */
+int mc_add_motion_term(mc_context* ctx, int spline, const double* W, int error_term_order);
+
+/* Optional, before mc_finalize: this process handles shard `rank` of `world` (terms are split into
+ * `world` contiguous time windows of equal estimated cost; pattern and slot numbering stay global so
+ * partial results from different ranks add element-wise).  No counterpart in the reference, whose
+ * only parallelism is boost threads over term ranges (LinearSystemSolver.cpp:50-78). */
+int mc_set_shard(mc_context* ctx, int rank, int world);
+
+/* LinearSystemSolver::initMatrixStructure + BlockCholeskyLinearSystemSolver::initMatrixStructureImplementation
+ * (LinearSystemSolver.cpp:117-138, BlockCholeskyLinearSystemSolver.cpp:34-55) plus the symbolic part of
+ * SparseBlockMatrix::fillCCS (sparse_block_matrix.hpp:704-729): assigns block indices / column bases to
+ * active design variables, row bases to terms, and builds the upper-triangular block pattern (including
+ * every diagonal block and the structurally-zero blocks of padded spline coefficients). */
+int mc_finalize(mc_context* ctx);
+int mc_dims(const mc_context* ctx, int* j_rows, int* j_cols, int* n_blocks, int* n_terms, int* nnz);
+int mc_dv_block(const mc_context* ctx, int dv, int* block_index, int* column_base);
+/* scalar CCS pattern of the upper triangle: Cp[j_cols+1], Ci[nnz] -- bit-exact fillCCS ordering */
+int mc_get_pattern(const mc_context* ctx, int* Cp, int* Ci);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* LinearSystemSolver::evaluateError (LinearSystemSolver.cpp:81-92): returns J = sum w(chi2) chi2 in
+ * *J_out and, if e_out != NULL, e (j_rows doubles, = -sqrt(w) sqrtInvR^T e per term). */
+int mc_evaluate_error(mc_context* ctx, int use_mestimator, double* J_out, double* e_out);
+/* BlockCholeskyLinearSystemSolver::buildSystem (BlockCholeskyLinearSystemSolver.cpp:58-72) followed by
+ * fillCCS values: Cx_out[nnz] in the order of mc_get_pattern, rhs_out[j_cols].  Either may be NULL. */
+int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double* rhs_out);
+/* Same two operations writing into caller-owned DEVICE buffers, enqueued on `stream` (a hipStream_t)
+ * without synchronising: d_J (1 double), d_e (j_rows or NULL), d_Cx (nnz), d_rhs (j_cols).  The buffers
+ * are zeroed by the call.  With shards, the caller sums d_J/d_Cx/d_rhs over ranks (RCCL all-reduce). */
+int mc_evaluate_error_device(mc_context* ctx, int use_mestimator, double* d_J, double* d_e, void* stream);
+int mc_build_system_device(mc_context* ctx, int use_mestimator, double* d_Cx, double* d_rhs, void* stream);
+/* per-term raw chi^2 of the last mc_evaluate_error (ErrorTerm::getRawSquaredError) */
+int mc_get_term_chi2(mc_context* ctx, double* chi2_out);
+
+/* Optimizer2::applyStateUpdate / revertLastStateUpdate (Optimizer2.cpp:292-320): dx has j_cols entries. */
+int mc_apply_update(mc_context* ctx, const double* dx);
+int mc_revert_update(mc_context* ctx);
+/* current parameters of a design variable (DesignVariable::getParameters); returns the count.
+ * EUCLIDEAN_DIRECTION reports its 3x3 rotation (row major) followed by the magnitude. */
+int mc_get_dv_params(mc_context* ctx, int dv, double* out);
+/* asynchronous device errors raised by the last kernels (e.g. "Spline Coefficient Buffer Exceeded",
+ * BSplineExpressions.cpp:447): 0 = none. */
+int mc_device_status(mc_context* ctx);
+
+/* number of multiprocessors etc. for reports; returns 0 and fills what it can */
+int mc_device_info(mc_context* ctx, char* name, int name_len, int* n_cu, double* hbm_gib);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULTICAL_HIP_H */

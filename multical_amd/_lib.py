@@ -1,0 +1,71 @@
+"""ctypes binding of the C ABI in include/multical_hip.h.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no
+CPU fallback: if the library is missing or no HIP device is present the backend raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmulticalhip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); kept in one table so the tests can check it against the header
+SIGNATURES = {
+    "mc_create": (_ctx, [C.c_int]),
+    "mc_destroy": (None, [_ctx]),
+    "mc_last_error": (C.c_char_p, [_ctx]),
+    "mc_add_design_variable": (C.c_int, [_ctx, C.c_int, _dp, C.c_int, C.c_int, C.c_double]),
+    "mc_add_spline": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int]),
+    "mc_spline_first_dv": (C.c_int, [_ctx, C.c_int]),
+    "mc_add_camera": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mc_add_reprojection_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip, _ip, _ip,
+                                            _dp, _dp, _dp, C.c_double, C.c_int, C.c_double]),
+    "mc_add_static_reprojection_batch": (C.c_int, [_ctx, C.c_int, C.c_int, _ip, _ip, C.c_int, _ip, _ip, _ip, _dp, _dp, _dp,
+                                                   C.c_int, C.c_double]),
+    "mc_add_accelerometer_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                                             _dp, C.c_int, C.c_double]),
+    "mc_add_gyroscope_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int,
+                                         C.c_double]),
+    "mc_add_lidar_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip,
+                                     C.c_double, C.c_int, C.c_double]),
+    "mc_add_motion_term": (C.c_int, [_ctx, C.c_int, _dp, C.c_int]),
+    "mc_set_shard": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "mc_finalize": (C.c_int, [_ctx]),
+    "mc_dims": (C.c_int, [_ctx, _ip, _ip, _ip, _ip, _ip]),
+    "mc_dv_block": (C.c_int, [_ctx, C.c_int, _ip, _ip]),
+    "mc_get_pattern": (C.c_int, [_ctx, _ip, _ip]),
+    "mc_evaluate_error": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
+    "mc_build_system": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
+    "mc_evaluate_error_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mc_build_system_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mc_get_term_chi2": (C.c_int, [_ctx, _dp]),
+    "mc_apply_update": (C.c_int, [_ctx, _dp]),
+    "mc_revert_update": (C.c_int, [_ctx]),
+    "mc_get_dv_params": (C.c_int, [_ctx, C.c_int, _dp]),
+    "mc_device_status": (C.c_int, [_ctx]),
+    "mc_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, _ip, _dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmulticalhip.so (once) and declare every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "multical_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

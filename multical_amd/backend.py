@@ -1,0 +1,446 @@
+"""Host-side mirror of the reference's solver interface for the HIP backend.
+
+`HipApi` is a 1:1 wrapper over the C ABI (include/multical_hip.h).  `HipBlockCholeskyLinearSystemSolver`,
+`LevenbergMarquardtTrustRegionPolicy`, `Optimizer2Options` and `Optimizer2` keep the names, argument meaning and
+control flow of the reference classes they stand in for:
+
+  aslam_backend/include/aslam/backend/LinearSystemSolver.hpp:16-109
+  aslam_backend/src/BlockCholeskyLinearSystemSolver.cpp:34-106,172-176
+  aslam_backend/src/LevenbergMarquardtTrustRegionPolicy.cpp:38-113, src/TrustRegionPolicy.cpp:29-57
+  aslam_backend/src/Optimizer2.cpp:183-320, include/aslam/backend/Optimizer2Options.hpp:9-42
+
+The residual / Jacobian / normal-equation work runs on the GPU; the sparse Cholesky solve stays on the host
+(north_star: "timed separately").  CHOLMOD is not installed here, so `solveSystem` factorises the same CCS
+matrix with SuperLU (scipy) in symmetric mode; the reference's own tests pin the solver only through
+solver-vs-solver agreement of dx (aslam_backend/test/LinearSolverTests.cpp:42-57).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class BackendError(RuntimeError):
+    """aslam::Exception stand-in (SM_DEFINE_EXCEPTION, LinearSystemSolver.hpp:18)."""
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class HipApi(object):
+    """Thin object wrapper over the C ABI; every method is one C call."""
+
+    def __init__(self, device=-1):
+        self.lib = _lib.load()
+        self.ctx = self.lib.mc_create(device)
+        if not self.ctx:
+            raise BackendError("mc_create failed: %s" % self.lib.mc_last_error(None).decode())
+        self.finalized = False
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise BackendError(self.lib.mc_last_error(self.ctx).decode())
+        return rc
+
+    # ---- description
+    def add_design_variable(self, kind, params, active=True, scaling=1.0):
+        p = _f64(params)
+        return self._chk(self.lib.mc_add_design_variable(self.ctx, kind, _dp(p), p.size, int(bool(active)), float(scaling)))
+
+    def add_spline(self, order, dim, knots, coeffs, active=True):
+        k = _f64(knots)
+        c = np.ascontiguousarray(_f64(coeffs).T)   # dim x n -> n x dim rows == column-major dim x n
+        return self._chk(self.lib.mc_add_spline(self.ctx, order, dim, _dp(k), k.size, _dp(c), c.shape[0], int(bool(active))))
+
+    def spline_first_dv(self, sid):
+        return self.lib.mc_spline_first_dv(self.ctx, sid)
+
+    def add_camera(self, model, dist, dv_proj, dv_dist=-1):
+        return self._chk(self.lib.mc_add_camera(self.ctx, model, dist, dv_proj, dv_dist))
+
+    def add_reprojection_batch(self, cam, spline, dv_q_cb, dv_t_cb, dv_toff, obs_time, obs_q, obs_t, obs_first, y, p, sinv, pad,
+                               mest=0, mest_param=0.0):
+        obs_time, y, p, sinv = _f64(obs_time), _f64(y), _f64(p), _f64(sinv)
+        obs_q, obs_t, obs_first = _i32(obs_q), _i32(obs_t), _i32(obs_first)
+        assert obs_first.size == obs_time.size + 1 and y.size == 2 * sinv.size and p.size == 3 * sinv.size
+        self._chk(self.lib.mc_add_reprojection_batch(self.ctx, cam, spline, dv_q_cb, dv_t_cb, dv_toff, obs_time.size,
+                                                     _dp(obs_time), _ip(obs_q), _ip(obs_t), _ip(obs_first), _dp(y), _dp(p),
+                                                     _dp(sinv), float(pad), mest, float(mest_param)))
+
+    def add_static_reprojection_batch(self, cam, chain_q, chain_t, obs_q, obs_t, obs_first, y, p, sinv, mest=0, mest_param=0.0):
+        y, p, sinv = _f64(y), _f64(p), _f64(sinv)
+        chain_q, chain_t, obs_q, obs_t, obs_first = _i32(chain_q), _i32(chain_t), _i32(obs_q), _i32(obs_t), _i32(obs_first)
+        self._chk(self.lib.mc_add_static_reprojection_batch(self.ctx, cam, chain_q.size, _ip(chain_q), _ip(chain_t), obs_q.size,
+                                                            _ip(obs_q), _ip(obs_t), _ip(obs_first), _dp(y), _dp(p), _dp(sinv),
+                                                            mest, float(mest_param)))
+
+    def add_accelerometer_batch(self, pose_spline, bias_spline, dv_bias, dv_g, dv_q_ib, dv_r_b, t, meas, sinv, mest=0,
+                                mest_param=0.0):
+        t, meas, sinv = _f64(t), _f64(meas), _f64(sinv)
+        self._chk(self.lib.mc_add_accelerometer_batch(self.ctx, pose_spline, bias_spline, dv_bias, dv_g, dv_q_ib, dv_r_b, t.size,
+                                                      _dp(t), _dp(meas), _dp(sinv), mest, float(mest_param)))
+
+    def add_gyroscope_batch(self, pose_spline, bias_spline, dv_bias, dv_q_ib, t, meas, sinv, mest=0, mest_param=0.0):
+        t, meas, sinv = _f64(t), _f64(meas), _f64(sinv)
+        self._chk(self.lib.mc_add_gyroscope_batch(self.ctx, pose_spline, bias_spline, dv_bias, dv_q_ib, t.size, _dp(t), _dp(meas),
+                                                  _dp(sinv), mest, float(mest_param)))
+
+    def add_lidar_batch(self, spline, dv_toff, dv_q_lb, dv_t_lb, t, direction, rng, sinv, dv_q_pw, dv_t_pw, pad, mest=0,
+                        mest_param=0.0):
+        t, direction, rng, sinv = _f64(t), _f64(direction), _f64(rng), _f64(sinv)
+        dv_q_pw, dv_t_pw = _i32(dv_q_pw), _i32(dv_t_pw)
+        self._chk(self.lib.mc_add_lidar_batch(self.ctx, spline, dv_toff, dv_q_lb, dv_t_lb, t.size, _dp(t), _dp(direction),
+                                              _dp(rng), _dp(sinv), _ip(dv_q_pw), _ip(dv_t_pw), float(pad), mest,
+                                              float(mest_param)))
+
+    def add_motion_term(self, spline, W, order):
+        W = _f64(W)
+        self._chk(self.lib.mc_add_motion_term(self.ctx, spline, _dp(W), order))
+
+    def set_shard(self, rank, world):
+        self._chk(self.lib.mc_set_shard(self.ctx, rank, world))
+
+    # ---- structure
+    def finalize(self):
+        self._chk(self.lib.mc_finalize(self.ctx))
+        v = [C.c_int() for _ in range(5)]
+        self.lib.mc_dims(self.ctx, *[C.byref(x) for x in v])
+        self.j_rows, self.j_cols, self.n_blocks, self.n_terms, self.nnz = [x.value for x in v]
+        self.finalized = True
+
+    def dv_block(self, dv):
+        b, c = C.c_int(), C.c_int()
+        self._chk(self.lib.mc_dv_block(self.ctx, dv, C.byref(b), C.byref(c)))
+        return b.value, c.value
+
+    def pattern(self):
+        Cp = np.empty(self.j_cols + 1, np.int32)
+        Ci = np.empty(self.nnz, np.int32)
+        self._chk(self.lib.mc_get_pattern(self.ctx, _ip(Cp), _ip(Ci)))
+        return Cp, Ci
+
+    # ---- hot path
+    def evaluate_error(self, use_mest=True, want_e=True):
+        J = C.c_double()
+        e = np.empty(self.j_rows) if want_e else None
+        self._chk(self.lib.mc_evaluate_error(self.ctx, int(use_mest), C.byref(J), _dp(e)))
+        self.check_status()
+        return J.value, e
+
+    def build_system(self, use_mest=True):
+        Cx = np.empty(self.nnz)
+        rhs = np.empty(self.j_cols)
+        self._chk(self.lib.mc_build_system(self.ctx, int(use_mest), _dp(Cx), _dp(rhs)))
+        self.check_status()
+        return Cx, rhs
+
+    def evaluate_error_device(self, use_mest, d_J, d_e, stream):
+        self._chk(self.lib.mc_evaluate_error_device(self.ctx, int(use_mest), d_J, d_e, stream))
+
+    def build_system_device(self, use_mest, d_Cx, d_rhs, stream):
+        self._chk(self.lib.mc_build_system_device(self.ctx, int(use_mest), d_Cx, d_rhs, stream))
+
+    def term_chi2(self):
+        out = np.empty(self.n_terms)
+        self._chk(self.lib.mc_get_term_chi2(self.ctx, _dp(out)))
+        return out
+
+    def apply_update(self, dx):
+        dx = _f64(dx)
+        assert dx.size == self.j_cols
+        self._chk(self.lib.mc_apply_update(self.ctx, _dp(dx)))
+
+    def revert_update(self):
+        self._chk(self.lib.mc_revert_update(self.ctx))
+
+    def dv_params(self, dv):
+        out = np.empty(16)
+        n = self._chk(self.lib.mc_get_dv_params(self.ctx, dv, _dp(out)))
+        return out[:n].copy()
+
+    def check_status(self):
+        s = self._chk(self.lib.mc_device_status(self.ctx))
+        if s:
+            raise BackendError(self.lib.mc_last_error(self.ctx).decode())
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu, gib = C.c_int(), C.c_double()
+        self._chk(self.lib.mc_device_info(self.ctx, name, 256, C.byref(ncu), C.byref(gib)))
+        return name.value.decode(), ncu.value, gib.value
+
+
+# ------------------------------------------------------------------------------------------------
+class HostSparseCholesky(object):
+    """Stand-in for sparse_block_matrix::LinearSolverCholmod::solve (linear_solver_cholmod.h:70-112) on the host.
+    Takes the upper-triangular CCS (Cp, Ci, Cx); returns None when the matrix is not positive definite."""
+
+    def __init__(self):
+        self.perm_spec = "MMD_AT_PLUS_A"
+
+    def solve(self, n, Cp, Ci, Cx, b):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        U = sp.csc_matrix((Cx, Ci, Cp), shape=(n, n))
+        A = (U + sp.triu(U, 1).T).tocsc()
+        try:
+            lu = spla.splu(A, permc_spec=self.perm_spec, diag_pivot_thresh=0.0,
+                           options=dict(SymmetricMode=True))
+        except RuntimeError:
+            return None
+        d = lu.U.diagonal()
+        if not np.all(np.isfinite(d)) or np.any(d <= 0.0):   # no row pivoting: U's diagonal = LDL^T pivots
+            return None
+        x = lu.solve(b)
+        return x if np.all(np.isfinite(x)) else None
+
+
+class HipBlockCholeskyLinearSystemSolver(object):
+    """LinearSystemSolver backend: same virtual surface as BlockCholeskyLinearSystemSolver."""
+
+    def __init__(self, api):
+        self.api = api
+        self._host = HostSparseCholesky()
+        self._useDiagonalConditioner = False
+        self._diag = None
+        self._Cx = None
+        self._rhs = None
+        self._e = None
+
+    def name(self):
+        return "hip_block_cholesky"
+
+    # LinearSystemSolver::initMatrixStructure -- the design-variable / error-term lists live in the context
+    def initMatrixStructure(self, useDiagonalConditioner):
+        if not self.api.finalized:
+            self.api.finalize()
+        self._useDiagonalConditioner = bool(useDiagonalConditioner)
+        self._Cp, self._Ci = self.api.pattern()
+        n = self.api.j_cols
+        self._diag_pos = self._Cp[1:] - 1          # last entry of every upper-triangular column = diagonal
+        self._diag = np.zeros(n)
+        self._Cx = np.zeros(self.api.nnz)
+        self._rhs = np.zeros(n)
+
+    def JRows(self):
+        return self.api.j_rows
+
+    def JCols(self):
+        return self.api.j_cols
+
+    def evaluateError(self, nThreads=1, useMEstimator=True):
+        J, self._e = self.api.evaluate_error(useMEstimator, want_e=True)
+        return J
+
+    def buildSystem(self, nThreads=1, useMEstimator=True):
+        self._Cx, self._rhs = self.api.build_system(useMEstimator)
+
+    def setConstantConditioner(self, diag):
+        self._diag = np.full(self.api.j_cols, float(diag))
+
+    def setConditioner(self, diag):
+        diag = _f64(diag)
+        if diag.size != self.api.j_cols:
+            raise BackendError("The diagonal conditioner must have the same number of rows as the Hessian matrix")
+        self._diag = diag.copy()
+
+    def solveSystem(self):
+        """Returns (success, dx).  Reproduces the augment-by-lambda^2 / un-augment-by-lambda sequence of
+        BlockCholeskyLinearSystemSolver.cpp:76-98 on the host copy of H."""
+        if self._useDiagonalConditioner:
+            self._Cx[self._diag_pos] += self._diag * self._diag
+        x = self._host.solve(self.api.j_cols, self._Cp, self._Ci, self._Cx, self._rhs)
+        if self._useDiagonalConditioner:
+            self._Cx[self._diag_pos] -= self._diag
+        if x is None:
+            return False, np.zeros(self.api.j_cols)
+        return True, x
+
+    def rhs(self):
+        return self._rhs
+
+    def e(self):
+        return self._e
+
+    def Hessian(self):
+        import scipy.sparse as sp
+        n = self.api.j_cols
+        U = sp.csc_matrix((self._Cx, self._Ci, self._Cp), shape=(n, n))
+        return U
+
+    def rhsJtJrhs(self):
+        import scipy.sparse as sp
+        U = self.Hessian()
+        A = U + sp.triu(U, 1).T
+        return float(self._rhs @ (A @ self._rhs))
+
+
+class LevenbergMarquardtTrustRegionPolicy(object):
+    def __init__(self, lambdaInit=1e-3):
+        self._lambdaInit, self._gammaInit, self._betaInit, self._pInit, self._muInit = lambdaInit, 3.0, 2.0, 3, 2.0
+        self._solver = None
+
+    def name(self):
+        return "levenberg_marquardt"
+
+    def setSolver(self, solver):
+        self._solver = solver
+
+    def requiresAugmentedDiagonal(self):
+        return True
+
+    def revertOnFailure(self):
+        return True
+
+    def optimizationStarting(self, J):
+        self._J = self._p_J = self._last_successful_J = J
+        self._isFirstIteration = True
+        self._lambda, self._gamma, self._beta, self._p, self._mu = (self._lambdaInit, self._gammaInit, self._betaInit,
+                                                                    self._pInit, self._muInit)
+        self._dx = None
+
+    def solveSystem(self, J, previousIterationFailed, nThreads):
+        if previousIterationFailed:
+            self._J = J
+        else:
+            self._p_J = self._last_successful_J
+            self._last_successful_J = J
+            self._J = J
+        if self._isFirstIteration:
+            self._solver.buildSystem(nThreads, True)
+        else:
+            d1 = self._p_J - self._J
+            d2 = float(self._dx @ (self._lambda * self._dx + self._solver.rhs()))
+            rho = d1 / d2
+            if previousIterationFailed:
+                self._mu *= 2
+                self._lambda *= self._mu
+            elif rho <= 0:
+                self._mu *= 10
+                self._lambda *= self._mu
+            else:
+                self._solver.buildSystem(nThreads, True)
+                if self._lambda > 1e-16:
+                    u1 = 1 / self._gamma
+                    u2 = 1 - (self._beta - 1) * (2 * rho - 1) ** self._p
+                    self._lambda *= u1 if u1 > u2 else u2
+                    self._mu = self._beta
+                else:
+                    self._lambda = 1e-15
+        self._solver.setConstantConditioner(self._lambda)
+        ok, self._dx = self._solver.solveSystem()
+        self._isFirstIteration = False
+        return ok, self._dx
+
+
+class Optimizer2Options(object):
+    def __init__(self):
+        self.convergenceDeltaX = 1e-3
+        self.convergenceJDescentRatioThreshold = 1e-3
+        self.maxIterations = 20
+        self.levenbergMarquardtLambdaInit = 1e-3
+        self.doLevenbergMarquardt = True
+        self.verbose = False
+        self.nThreads = 4
+        self.linearSolver = None
+        self.trustRegionPolicy = None
+
+
+class SolutionReturnValue(object):
+    def __init__(self):
+        self.JStart = self.JFinal = self.dXFinal = self.dJFinal = 0.0
+        self.iterations = self.failedIterations = 0
+        self.linearSolverFailure = False
+
+
+class Optimizer2(object):
+    def __init__(self, options):
+        self._options = options
+        self.timings = dict(evaluateError=0.0, buildSystem=0.0, solveSystem=0.0, update=0.0)
+
+    def optimize(self):
+        import time
+        o = self._options
+        solver = o.linearSolver
+        if solver is None:
+            raise BackendError("Optimizer2Options.linearSolver must be a HipBlockCholeskyLinearSystemSolver")
+        policy = o.trustRegionPolicy or LevenbergMarquardtTrustRegionPolicy(o.levenbergMarquardtLambdaInit)
+        solver.initMatrixStructure(policy.requiresAugmentedDiagonal())
+        srv = SolutionReturnValue()
+        tm = self.timings
+        t0 = time.perf_counter()
+        J = solver.evaluateError(o.nThreads, True)
+        tm["evaluateError"] += time.perf_counter() - t0
+        p_J = J
+        srv.JStart = p_J
+        deltaX = o.convergenceDeltaX + 1.0
+        ratio = o.convergenceJDescentRatioThreshold + 1.0
+        deltaJ = 0.0
+        prevFailed = lsFail = False
+        policy.setSolver(solver)
+        policy.optimizationStarting(J)
+        while (srv.iterations < o.maxIterations and srv.failedIterations < o.maxIterations and
+               ((deltaX > o.convergenceDeltaX and abs(ratio) > o.convergenceJDescentRatioThreshold) or lsFail)):
+            t0 = time.perf_counter()
+            b0 = tm["buildSystem"]
+            _build = solver.buildSystem
+
+            def timed_build(n, m, _b=_build):
+                t1 = time.perf_counter()
+                _b(n, m)
+                tm["buildSystem"] += time.perf_counter() - t1
+            solver.buildSystem = timed_build
+            ok, dx = policy.solveSystem(J, prevFailed, o.nThreads)
+            solver.buildSystem = _build
+            tm["solveSystem"] += time.perf_counter() - t0 - (tm["buildSystem"] - b0)
+            if not ok:
+                prevFailed = lsFail = True
+                srv.failedIterations += 1
+            else:
+                t0 = time.perf_counter()
+                solver.api.apply_update(dx)
+                deltaX = float(np.max(np.abs(dx)))
+                tm["update"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                J = solver.evaluateError(o.nThreads, True)
+                tm["evaluateError"] += time.perf_counter() - t0
+                deltaJ = p_J - J
+                ratio = deltaJ / p_J
+                if ratio < 0.0:
+                    solver.api.revert_update()
+                    srv.failedIterations += 1
+                    prevFailed = True
+                else:
+                    p_J = J
+                    prevFailed = False
+                srv.iterations += 1
+                if o.verbose:
+                    print("[%d]: J: %.9g, dJ: %.6g, deltaX: %.6g, LM - lambda:%g mu:%g" %
+                          (srv.iterations, J, deltaJ, deltaX, policy._lambda, policy._mu))
+        srv.JFinal, srv.dXFinal, srv.dJFinal, srv.linearSolverFailure = p_J, deltaX, deltaJ, lsFail
+        return srv

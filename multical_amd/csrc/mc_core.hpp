@@ -1,0 +1,513 @@
+// mc_core.hpp -- host-side problem description and structure analysis (no HIP in this file).
+//
+// What the reference does lazily and per call -- Optimizer2::initialize (block indices, column bases,
+// row bases; aslam_backend/src/Optimizer2.cpp:95-151), first-touch allocation of Hessian blocks inside
+// SparseBlockMatrix::block(r, c, true) (sparse_block_matrix.hpp:121-143) and the symbolic half of fillCCS
+// (:704-729) -- is done here once per optimize(): the term batches are cut into *groups* of terms that
+// touch the same Hessian blocks, each distinct block list (*footprint*) gets a table of value offsets
+// into the final CCS array, and the scalar pattern (Cp, Ci) is emitted in exactly fillCCS order.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "mc_terms.h"
+
+namespace mc {
+
+enum { DV_EUCLIDEAN_POINT = 0, DV_ROTATION_QUATERNION = 1, DV_SCALAR = 2, DV_EUCLIDEAN_DIRECTION = 3,
+       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6 };
+enum { KIND_REPROJ = 0, KIND_STATIC_REPROJ = 1, KIND_ACCEL = 2, KIND_GYRO = 3, KIND_LIDAR = 4, KIND_MOTION = 5 };
+
+struct DvRec {
+  int kind, dim, off, nparam, active;
+  double scaling;
+  int block = -1, col = -1;
+  int spline = -1;
+};
+struct SplineRec {
+  int order, dim, n_knots, n_coeff, n_seg, first_dv, param_off, knots_off, basis_off, active;
+  double t_min, t_max;
+};
+struct CameraRec { int model, dist, dv_proj, dv_dist; };
+
+// A group = consecutive terms of one batch that write the same Hessian blocks.
+struct GroupRec {
+  int term_first, term_count;
+  int fp;    // footprint id
+  int aux;   // kind specific (F1: observation index)
+};
+
+struct Batch {
+  int kind;
+  int n_terms = 0, dim = 0, row_base = 0, term_base = 0;
+  int mest = 0; double mest_a = 0;
+  // shared ids
+  int cam = -1, spline = -1, bias_spline = -1;
+  int dv[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // kind specific global dvs
+  double pad = 0;
+  // per-term / per-observation host arrays
+  std::vector<double> t, y, p, sinv, meas, range;
+  std::vector<int> obs_first, obs_dv_q, obs_dv_t, term_dv_q, term_dv_t, term_obs;
+  std::vector<int> chain_q, chain_t;
+  // motion term
+  std::vector<double> Qband;  // n_coeff x S blocks of dim x dim, Qband[(i*S + d)*D*D ...] = Q(i, i-d)
+  int motion_order = 0;
+  // structure (filled by finalize)
+  std::vector<GroupRec> groups;       // all groups (terms numbered within the batch)
+  std::vector<GroupRec> my_groups;    // the groups of this rank's time window
+  std::vector<double> group_time;     // representative time per group (for sharding)
+};
+
+// footprint layout in the flat int array `fp_data` at fp_off[f]:
+//   [0] nb   [1] C (local columns)   [2] first buffered spline coefficient, [3] number of buffered coefficients (time-offset kinds)
+//   [4 .. 4+MC_MAX_ROLES) rolecol
+//   then nb x (block index, local col start, block dim, global column base)
+//   then nb(nb+1)/2 slot bases, pair (ia <= ib) at ib(ib+1)/2 + ia
+//   then C bytes-as-ints: block position of each local column
+enum { FP_HDR = 4 + MC_MAX_ROLES };
+
+struct Problem {
+  std::vector<DvRec> dvs;
+  std::vector<double> x;        // state vector (all parameters)
+  std::vector<SplineRec> splines;
+  std::vector<double> knots, basis;
+  std::vector<CameraRec> cams;
+  std::vector<Batch> batches;
+  int rank = 0, world = 1;
+  double shard_lo = -INFINITY, shard_hi = INFINITY;
+
+  // structure
+  bool finalized = false;
+  int n_blocks = 0, j_cols = 0, j_rows = 0, n_terms = 0, nnz = 0;
+  std::vector<int> block_dim, block_col, block_dv;
+  std::vector<std::vector<int>> col_rows;   // per block column: sorted row blocks (upper triangle incl. diagonal)
+  std::vector<std::vector<int>> col_roff;   // scalar row offset of each of those blocks inside a scalar column
+  std::vector<int> col_h;                   // total rows of the strictly-upper blocks of a block column
+  std::vector<int> Cp, Ci;
+  std::vector<int> fp_data, fp_off;
+  std::unordered_map<std::string, int> fp_lookup;
+  std::vector<int> update_dvs;              // active dvs in block order
+
+  // ------------------------------------------------------------------ description
+  int addDv(int kind, const double* params, int n, int active, double scaling) {
+    DvRec d;
+    d.kind = kind; d.active = active ? 1 : 0; d.scaling = scaling; d.off = (int)x.size();
+    switch (kind) {
+      case DV_EUCLIDEAN_POINT: if (n != 3) throw std::invalid_argument("EuclideanPoint needs 3 parameters"); d.dim = 3; d.nparam = 3; break;
+      case DV_ROTATION_QUATERNION: if (n != 4) throw std::invalid_argument("RotationQuaternion needs 4 parameters"); d.dim = 3; d.nparam = 4; break;
+      case DV_SCALAR: if (n != 1) throw std::invalid_argument("Scalar needs 1 parameter"); d.dim = 1; d.nparam = 1; break;
+      case DV_EUCLIDEAN_DIRECTION: if (n != 3) throw std::invalid_argument("EuclideanDirection needs a 3-vector"); d.dim = 2; d.nparam = 10; break;
+      case DV_PROJECTION: if (n < 4 || n > 6) throw std::invalid_argument("projection needs 4..6 parameters"); d.dim = n; d.nparam = n; break;
+      case DV_DISTORTION: if (n != 4) throw std::invalid_argument("distortion needs 4 parameters"); d.dim = 4; d.nparam = 4; break;
+      default: throw std::invalid_argument("unknown design variable kind");
+    }
+    if (kind == DV_EUCLIDEAN_DIRECTION) {
+      // EuclideanDirection constructor (ABE/src/EuclideanDirection.cpp:5-17): C = R_ypr(0, asin(-u0), atan2(u1,u2))^T
+      double m = std::sqrt(params[0] * params[0] + params[1] * params[1] + params[2] * params[2]);
+      if (!(m > 0.0)) throw std::invalid_argument("The pointing vector must have a magnitude greater than zero");
+      double u0 = params[0] / m, u1 = params[1] / m, u2 = params[2] / m;
+      double R[9];
+      ypr0_to_r(std::asin(-u0), std::atan2(u1, u2), R);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) x.push_back(R[3 * j + i]);
+      x.push_back(m);
+    } else {
+      x.insert(x.end(), params, params + n);
+    }
+    dvs.push_back(d);
+    return (int)dvs.size() - 1;
+  }
+
+  // BSpline::M recursion (BSP/src/BSpline.cpp:70-149), evaluated bottom-up for one segment
+  static void basisMatrix(const std::vector<double>& kn, int order, int i, double* out /* S x S row-major */) {
+    std::vector<double> M(1, 1.0);
+    for (int k = 2; k <= order; ++k) {
+      std::vector<double> N((size_t)k * k, 0.0);
+      // N = [M;0] A + [0;M] B with A,B (k-1) x k
+      for (int idx = 0; idx < k - 1; ++idx) {
+        int j = i - k + 2 + idx;
+        double denom = kn[j + k - 1] - kn[j];
+        double d0 = denom <= 0.0 ? 0.0 : (kn[i] - kn[j]) / denom;
+        double d1 = denom <= 0.0 ? 0.0 : (kn[i + 1] - kn[i]) / denom;
+        for (int r = 0; r < k - 1; ++r) {
+          double m = M[(size_t)r * (k - 1) + idx];
+          // [M;0] * A : row r
+          N[(size_t)r * k + idx] += m * (1.0 - d0);
+          N[(size_t)r * k + idx + 1] += m * d0;
+          // [0;M] * B : row r+1
+          N[(size_t)(r + 1) * k + idx] += m * (-d1);
+          N[(size_t)(r + 1) * k + idx + 1] += m * d1;
+        }
+      }
+      M.swap(N);
+    }
+    std::memcpy(out, M.data(), sizeof(double) * order * order);
+  }
+
+  int addSpline(int order, int dim, const double* kn, int n_knots, const double* coeffs, int n_coeff, int active) {
+    if (order != S6) throw std::invalid_argument("the HIP path handles spline order 6 (Multical's splineOrder); got another order");
+    if (dim != 6 && dim != 3) throw std::invalid_argument("spline dimension must be 6 (pose) or 3 (euclidean)");
+    int n_seg = n_knots - 2 * order + 1;
+    if (n_seg < 1 || n_seg + order - 1 != n_coeff) throw std::invalid_argument("knot / coefficient count mismatch");
+    for (int i = 1; i < n_knots; ++i) if (kn[i - 1] > kn[i]) throw std::invalid_argument("The knot sequence must be nondecreasing");
+    SplineRec s;
+    s.order = order; s.dim = dim; s.n_knots = n_knots; s.n_coeff = n_coeff; s.n_seg = n_seg; s.active = active ? 1 : 0;
+    s.first_dv = (int)dvs.size(); s.param_off = (int)x.size();
+    s.knots_off = (int)knots.size(); s.basis_off = (int)basis.size();
+    s.t_min = kn[order - 1]; s.t_max = kn[n_knots - order];
+    knots.insert(knots.end(), kn, kn + n_knots);
+    std::vector<double> kv(kn, kn + n_knots);
+    basis.resize(basis.size() + (size_t)n_seg * order * order);
+    for (int sgm = 0; sgm < n_seg; ++sgm) basisMatrix(kv, order, sgm + order - 1, &basis[s.basis_off + (size_t)sgm * order * order]);
+    for (int i = 0; i < n_coeff; ++i) {
+      DvRec d;
+      d.kind = DV_SPLINE_COEFF; d.dim = dim; d.nparam = dim; d.active = s.active; d.scaling = 1.0;
+      d.off = (int)x.size(); d.spline = (int)splines.size();
+      x.insert(x.end(), coeffs + (size_t)i * dim, coeffs + (size_t)(i + 1) * dim);
+      dvs.push_back(d);
+    }
+    splines.push_back(s);
+    return (int)splines.size() - 1;
+  }
+  int addCamera(int model, int dist, int dv_proj, int dv_dist) {
+    checkDv(dv_proj, DV_PROJECTION);
+    int need = model == 0 ? 4 : (model == 1 ? 5 : 6);
+    if (model < 0 || model > 2 || dvs[dv_proj].nparam != need) throw std::invalid_argument("projection parameter count does not match the model");
+    if (dist < 0 || dist > 2) throw std::invalid_argument("unknown distortion model");
+    if (model == 2 && dist != 0) throw std::invalid_argument("double sphere takes no distortion");
+    if (dist != 0) checkDv(dv_dist, DV_DISTORTION);
+    cams.push_back(CameraRec{model, dist, dv_proj, dist != 0 ? dv_dist : -1});
+    return (int)cams.size() - 1;
+  }
+  void checkDv(int id, int kind) const {
+    if (id < 0 || id >= (int)dvs.size()) throw std::invalid_argument("design variable id out of range");
+    if (kind >= 0 && dvs[id].kind != kind) throw std::invalid_argument("design variable has the wrong kind for this role");
+  }
+  void checkSpline(int id, int dim) const {
+    if (id < 0 || id >= (int)splines.size()) throw std::invalid_argument("spline id out of range");
+    if (splines[id].dim != dim) throw std::invalid_argument("spline has the wrong dimension for this role");
+  }
+
+  // ------------------------------------------------------------------ views
+  SplineView splineView(int id, const double* d_knots, const double* d_basis) const {
+    SplineView v;
+    std::memset(&v, 0, sizeof v);
+    if (id < 0) return v;
+    const SplineRec& s = splines[id];
+    v.knots = d_knots + s.knots_off; v.basis = d_basis + s.basis_off;
+    v.n_knots = s.n_knots; v.order = s.order; v.dim = s.dim; v.n_coeff = s.n_coeff; v.n_seg = s.n_seg;
+    v.param_off = s.param_off;
+    v.first_block = dvs[s.first_dv].block; v.first_col = dvs[s.first_dv].col;
+    v.t_min = s.t_min; v.t_max = s.t_max;
+    return v;
+  }
+  DvRef dvRef(int id) const {
+    DvRef r{-1, -1, -1, 1.0};
+    if (id < 0) return r;
+    r.off = dvs[id].off; r.block = dvs[id].block; r.col = dvs[id].col; r.scale = dvs[id].scaling;
+    return r;
+  }
+  CameraView cameraView(int id) const {
+    const CameraRec& c = cams[id];
+    CameraView v;
+    v.model = c.model; v.dist = c.dist;
+    v.proj_off = dvs[c.dv_proj].off; v.proj_block = dvs[c.dv_proj].block; v.proj_col = dvs[c.dv_proj].col;
+    v.proj_dim = dvs[c.dv_proj].dim;
+    v.dist_off = c.dv_dist >= 0 ? dvs[c.dv_dist].off : -1;
+    v.dist_block = c.dv_dist >= 0 ? dvs[c.dv_dist].block : -1;
+    v.dist_col = c.dv_dist >= 0 ? dvs[c.dv_dist].col : -1;
+    return v;
+  }
+
+  // ------------------------------------------------------------------ structure
+  // segment index of t on the host (BSpline::segmentIndex)
+  int segmentOf(const SplineRec& s, double t) const {
+    SplineView v = splineView((int)(&s - &splines[0]), knots.data(), basis.data());
+    return spline_segment(v, t);
+  }
+  // TransformationTimeOffsetExpressionNode constructor (BSplineExpressions.cpp:406-437): coefficient range
+  // [lo, hi] frozen from the initial time +- padding.
+  void timeOffsetBuffer(const SplineRec& s, double t, double pad, int& lo, int& hi) const {
+    if (!(t >= s.t_min && t <= s.t_max)) throw std::invalid_argument("measurement time outside the spline");
+    int right = (pad + t > s.t_max) ? s.n_seg - 1 : segmentOf(s, t + pad);
+    int left = (t - pad < s.t_min) ? 0 : segmentOf(s, t - pad);
+    lo = left; hi = right + s.order - 1;
+  }
+
+  struct FpBuild {               // one footprint under construction
+    std::vector<int> pat_blocks; // every block of the term's design-variable set (pattern, incl. structural zeros)
+    std::vector<std::pair<int, int>> roles;  // (role, block index of the role's first block), active only
+    std::vector<int> role_nblocks;
+  };
+  // Registers (or finds) a footprint: `written` = list of (role, first block, n blocks); `pattern` = all blocks.
+  int internFootprint(const std::vector<int>& pattern, const std::vector<std::array<int, 3>>& written, int coefLo = 0, int nBuf = 0) {
+    std::string key;
+    key.reserve((pattern.size() + written.size() * 3 + 1) * 4);
+    auto put = [&](int v) { key.append((const char*)&v, 4); };
+    put((int)pattern.size());
+    for (int b : pattern) put(b);
+    for (auto& w : written) { put(w[0]); put(w[1]); put(w[2]); }
+    auto it = fp_lookup.find(key);
+    if (it != fp_lookup.end()) return it->second;
+    int id = (int)fp_pattern.size();
+    fp_lookup.emplace(std::move(key), id);
+    fp_pattern.push_back(pattern);
+    fp_written.push_back(written);
+    fp_coef_lo.push_back(coefLo);
+    fp_nbuf.push_back(nBuf);
+    return id;
+  }
+  std::vector<int> fp_coef_lo, fp_nbuf;
+  std::vector<std::vector<int>> fp_pattern;
+  std::vector<std::vector<std::array<int, 3>>> fp_written;
+
+  void finalize();
+};
+
+inline void Problem::finalize() {
+  if (finalized) throw std::logic_error("mc_finalize called twice");
+  // ---- Optimizer2::initialize: active dvs in problem order get block index / column base
+  n_blocks = 0; j_cols = 0;
+  block_dim.clear(); block_col.clear(); block_dv.clear();
+  for (size_t i = 0; i < dvs.size(); ++i) {
+    DvRec& d = dvs[i];
+    if (!d.active) { d.block = -1; d.col = -1; continue; }
+    d.block = n_blocks++; d.col = j_cols; j_cols += d.dim;
+    block_dim.push_back(d.dim); block_col.push_back(d.col); block_dv.push_back((int)i);
+  }
+  if (n_blocks == 0) throw std::runtime_error("It is illegal to run the optimizer with all marginalized design variables.");
+  if (batches.empty()) throw std::runtime_error("It is illegal to run the optimizer with no error terms.");
+  // ---- row bases
+  j_rows = 0; n_terms = 0;
+  for (Batch& b : batches) { b.row_base = j_rows; b.term_base = n_terms; j_rows += b.n_terms * b.dim; n_terms += b.n_terms; }
+
+  auto blk = [&](int dv) { return dv >= 0 ? dvs[dv].block : -1; };
+  // ---- groups + footprints per batch
+  for (Batch& b : batches) {
+    b.groups.clear(); b.group_time.clear();
+    auto pushGroup = [&](int first, int count, int fp, int aux, double time, int maxTerms) {
+      for (int o = 0; o < count; o += maxTerms) {
+        b.groups.push_back(GroupRec{first + o, std::min(maxTerms, count - o), fp, aux});
+        b.group_time.push_back(time);
+      }
+    };
+    if (b.kind == KIND_REPROJ || b.kind == KIND_LIDAR) {
+      const SplineRec& s = splines[b.spline];
+      int coef_block0 = dvs[s.first_dv].block;  // -1 if the spline is inactive
+      bool reproj = b.kind == KIND_REPROJ;
+      int n_units = reproj ? (int)b.obs_first.size() - 1 : b.n_terms;
+      int run_first = -1, run_fp = -1, run_count = 0;
+      double run_time = 0;
+      for (int u = 0; u < n_units; ++u) {
+        double t0 = b.t[u] + (b.dv[2] >= 0 ? x[dvs[b.dv[2]].off] : 0.0);
+        int lo, hi;
+        timeOffsetBuffer(s, t0, b.pad, lo, hi);
+        int seg = segmentOf(s, t0);
+        int dq = reproj ? b.obs_dv_q[u] : b.term_dv_q[u], dt = reproj ? b.obs_dv_t[u] : b.term_dv_t[u];
+        std::vector<int> pattern;
+        std::vector<std::array<int, 3>> written;
+        if (coef_block0 >= 0) {
+          // the active support moves with the time offset, so the whole frozen buffer [lo, hi] is laid out
+          // and the kernel places the 6 live coefficient blocks inside it at run time
+          for (int c = lo; c <= hi; ++c) pattern.push_back(coef_block0 + c);
+          written.push_back({0, coef_block0 + lo, hi - lo + 1});
+          (void)seg;
+        }
+        int gl[5] = {b.dv[0], b.dv[1], dq, dt, b.dv[2]};  // q_x_b, t_x_b, q_p_w, t_p_w, time offset
+        for (int g = 0; g < 5; ++g)
+          if (blk(gl[g]) >= 0) { pattern.push_back(blk(gl[g])); written.push_back({1 + g, blk(gl[g]), 1}); }
+        std::sort(pattern.begin(), pattern.end());
+        if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
+          throw std::invalid_argument("a design variable plays two roles in one error term");
+        int fp = internFootprint(pattern, written, lo, coef_block0 >= 0 ? hi - lo + 1 : 0);
+        if (reproj) {
+          pushGroup(b.obs_first[u], b.obs_first[u + 1] - b.obs_first[u], fp, u, b.t[u], 1 << 30);
+        } else {
+          // consecutive lidar points with the same footprint form one group (<= 48 terms)
+          if (run_count > 0 && (fp != run_fp || run_count == 48)) { pushGroup(run_first, run_count, run_fp, 0, run_time, 48); run_count = 0; }
+          if (run_count == 0) { run_first = u; run_fp = fp; run_time = b.t[u]; }
+          ++run_count;
+        }
+      }
+      if (!reproj && run_count > 0) pushGroup(run_first, run_count, run_fp, 0, run_time, 48);
+    } else if (b.kind == KIND_ACCEL || b.kind == KIND_GYRO) {
+      const SplineRec& s = splines[b.spline];
+      int coef_block0 = dvs[s.first_dv].block;
+      int run_first = -1, run_fp = -1, run_count = 0;
+      double run_time = 0;
+      for (int u = 0; u < b.n_terms; ++u) {
+        double t = b.t[u];
+        if (!(t >= s.t_min && t <= s.t_max)) throw std::invalid_argument("measurement time outside the pose spline");
+        int seg = segmentOf(s, t);
+        std::vector<int> pattern;
+        std::vector<std::array<int, 3>> written;
+        if (coef_block0 >= 0) {
+          for (int c = 0; c < s.order; ++c) pattern.push_back(coef_block0 + seg + c);
+          written.push_back({IMU_ROLE_POSE, coef_block0 + seg, s.order});
+        }
+        if (b.bias_spline >= 0) {
+          const SplineRec& bs = splines[b.bias_spline];
+          if (!(t >= bs.t_min && t <= bs.t_max)) throw std::invalid_argument("measurement time outside the bias spline");
+          int bb0 = dvs[bs.first_dv].block;
+          if (bb0 >= 0) {
+            int bseg = segmentOf(bs, t);
+            for (int c = 0; c < bs.order; ++c) pattern.push_back(bb0 + bseg + c);
+            written.push_back({IMU_ROLE_BIAS, bb0 + bseg, bs.order});
+          }
+        } else if (blk(b.dv[0]) >= 0) { pattern.push_back(blk(b.dv[0])); written.push_back({IMU_ROLE_BIAS, blk(b.dv[0]), 1}); }
+        if (b.kind == KIND_ACCEL && blk(b.dv[1]) >= 0) { pattern.push_back(blk(b.dv[1])); written.push_back({IMU_ROLE_G, blk(b.dv[1]), 1}); }
+        if (blk(b.dv[2]) >= 0) { pattern.push_back(blk(b.dv[2])); written.push_back({IMU_ROLE_QIB, blk(b.dv[2]), 1}); }
+        if (b.kind == KIND_ACCEL && blk(b.dv[3]) >= 0) { pattern.push_back(blk(b.dv[3])); written.push_back({IMU_ROLE_RB, blk(b.dv[3]), 1}); }
+        std::sort(pattern.begin(), pattern.end());
+        if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
+          throw std::invalid_argument("a design variable plays two roles in one error term");
+        int fp = internFootprint(pattern, written);
+        if (run_count > 0 && (fp != run_fp || run_count == 16)) { pushGroup(run_first, run_count, run_fp, 0, run_time, 16); run_count = 0; }
+        if (run_count == 0) { run_first = u; run_fp = fp; run_time = t; }
+        ++run_count;
+      }
+      if (run_count > 0) pushGroup(run_first, run_count, run_fp, 0, run_time, 16);
+    } else if (b.kind == KIND_STATIC_REPROJ) {
+      int n_obs = (int)b.obs_first.size() - 1;
+      const CameraRec& c = cams[b.cam];
+      for (int o = 0; o < n_obs; ++o) {
+        std::vector<int> pattern;
+        std::vector<std::array<int, 3>> written;
+        auto add = [&](int role, int dv) { if (blk(dv) >= 0) { pattern.push_back(blk(dv)); written.push_back({role, blk(dv), 1}); } };
+        add(F2_ROLE_QTC, b.obs_dv_q[o]); add(F2_ROLE_TTC, b.obs_dv_t[o]);
+        for (size_t j = 0; j < b.chain_q.size(); ++j) { add(F2_ROLE_CHAIN + 2 * (int)j, b.chain_q[j]); add(F2_ROLE_CHAIN + 2 * (int)j + 1, b.chain_t[j]); }
+        add(F2_ROLE_PROJ, c.dv_proj);
+        if (c.dv_dist >= 0) add(F2_ROLE_DIST, c.dv_dist);
+        std::sort(pattern.begin(), pattern.end());
+        if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
+          throw std::invalid_argument("a design variable plays two roles in one error term");
+        int fp = internFootprint(pattern, written);
+        pushGroup(b.obs_first[o], b.obs_first[o + 1] - b.obs_first[o], fp, o, (double)o, 24);
+      }
+    }
+  }
+  // ---- block pattern: union of all footprints' block pairs + every diagonal block
+  // (BlockCholeskyLinearSystemSolver::solveSystem touches block(i,i,true) for all i before fillCCS runs,
+  //  BlockCholeskyLinearSystemSolver.cpp:80-81)
+  col_rows.assign(n_blocks, std::vector<int>());
+  for (int i = 0; i < n_blocks; ++i) col_rows[i].push_back(i);
+  for (const std::vector<int>& pat : fp_pattern)
+    for (size_t j = 0; j < pat.size(); ++j)
+      for (size_t i = 0; i < j; ++i) col_rows[pat[j]].push_back(pat[i]);
+  // motion terms: band blocks between active coefficients (BSplineMotionError.hpp:122-156)
+  for (const Batch& b : batches) {
+    if (b.kind != KIND_MOTION) continue;
+    const SplineRec& s = splines[b.spline];
+    int b0 = dvs[s.first_dv].block;
+    if (b0 < 0) continue;
+    for (int i = 0; i < s.n_coeff; ++i)
+      for (int d = 1; d < s.order && i - d >= 0; ++d) col_rows[b0 + i].push_back(b0 + i - d);
+  }
+  col_roff.assign(n_blocks, std::vector<int>());
+  col_h.assign(n_blocks, 0);
+  Cp.assign(j_cols + 1, 0);
+  size_t total = 0;
+  for (int c = 0; c < n_blocks; ++c) {
+    std::vector<int>& rows = col_rows[c];
+    std::sort(rows.begin(), rows.end());
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    col_roff[c].resize(rows.size());
+    int off = 0;
+    for (size_t k = 0; k < rows.size(); ++k) { col_roff[c][k] = off; off += block_dim[rows[k]]; }
+    col_h[c] = off - block_dim[c];  // the diagonal block is the last one
+    for (int sc = 0; sc < block_dim[c]; ++sc) {
+      Cp[block_col[c] + sc] = (int)total;
+      total += (size_t)col_h[c] + sc + 1;
+    }
+    if (total > (size_t)0x7fffffff) throw std::overflow_error("Hessian pattern exceeds 2^31 scalar entries");
+  }
+  Cp[j_cols] = (int)total;
+  nnz = (int)total;
+  Ci.resize(nnz);
+  for (int c = 0; c < n_blocks; ++c)
+    for (int sc = 0; sc < block_dim[c]; ++sc) {
+      int* ci = &Ci[Cp[block_col[c] + sc]];
+      for (size_t k = 0; k < col_rows[c].size(); ++k) {
+        int rb = col_rows[c][k], n = (rb == c) ? sc + 1 : block_dim[rb];
+        for (int r = 0; r < n; ++r) *ci++ = block_col[rb] + r;
+      }
+    }
+  // ---- footprint tables
+  auto slotBase = [&](int rb, int cb) {
+    const std::vector<int>& rows = col_rows[cb];
+    size_t k = std::lower_bound(rows.begin(), rows.end(), rb) - rows.begin();
+    return Cp[block_col[cb]] + col_roff[cb][k];
+  };
+  fp_off.assign(fp_written.size(), 0);
+  fp_data.clear();
+  for (size_t f = 0; f < fp_written.size(); ++f) {
+    fp_off[f] = (int)fp_data.size();
+    // written blocks sorted by block index
+    std::vector<std::array<int, 3>> w = fp_written[f];
+    std::vector<std::pair<int, int>> blocks;  // (block index, role) expanded
+    std::vector<int> rolecol(MC_MAX_ROLES, -1);
+    for (auto& e : w) for (int k = 0; k < e[2]; ++k) blocks.push_back({e[1] + k, k == 0 ? e[0] : -1});
+    std::sort(blocks.begin(), blocks.end());
+    int nb = (int)blocks.size();
+    std::vector<int> colstart(nb + 1, 0);
+    for (int i = 0; i < nb; ++i) {
+      colstart[i + 1] = colstart[i] + block_dim[blocks[i].first];
+      if (blocks[i].second >= 0) rolecol[blocks[i].second] = colstart[i];
+    }
+    int C = colstart[nb];
+    fp_data.push_back(nb); fp_data.push_back(C);
+    fp_data.push_back(fp_coef_lo[f]); fp_data.push_back(fp_nbuf[f]);
+    for (int r = 0; r < MC_MAX_ROLES; ++r) fp_data.push_back(rolecol[r]);
+    for (int i = 0; i < nb; ++i) {
+      fp_data.push_back(blocks[i].first); fp_data.push_back(colstart[i]);
+      fp_data.push_back(block_dim[blocks[i].first]); fp_data.push_back(block_col[blocks[i].first]);
+    }
+    for (int ib = 0; ib < nb; ++ib)
+      for (int ia = 0; ia <= ib; ++ia) fp_data.push_back(slotBase(blocks[ia].first, blocks[ib].first));
+    for (int i = 0; i < nb; ++i)
+      for (int c = colstart[i]; c < colstart[i + 1]; ++c) fp_data.push_back(i);
+  }
+  // ---- shard: contiguous time windows of equal estimated cost over all groups
+  {
+    struct GT { double t; double cost; };
+    std::vector<GT> all;
+    for (const Batch& b : batches)
+      for (size_t g = 0; g < b.groups.size(); ++g) {
+        double per = b.kind == KIND_REPROJ ? 1.0 : (b.kind == KIND_LIDAR ? 1.5 : (b.kind == KIND_STATIC_REPROJ ? 1.0 : 4.0));
+        all.push_back(GT{b.group_time[g], 8.0 + per * b.groups[g].term_count});
+      }
+    std::vector<double> cuts(world + 1, 0.0);
+    cuts[0] = -INFINITY; cuts[world] = INFINITY;
+    if (world > 1 && !all.empty()) {
+      std::sort(all.begin(), all.end(), [](const GT& a, const GT& b2) { return a.t < b2.t; });
+      double tot = 0;
+      for (auto& g : all) tot += g.cost;
+      double acc = 0;
+      int r = 1;
+      for (size_t i = 0; i < all.size() && r < world; ++i) {
+        acc += all[i].cost;
+        while (r < world && acc >= tot * r / world) { cuts[r] = (i + 1 < all.size()) ? 0.5 * (all[i].t + all[i + 1].t) : INFINITY; ++r; }
+      }
+      for (; r < world; ++r) cuts[r] = INFINITY;
+    }
+    shard_lo = cuts[rank]; shard_hi = cuts[rank + 1];
+    for (Batch& b : batches) {
+      // keep the groups whose time falls into [lo, hi); group order inside a batch is preserved
+      std::vector<GroupRec> mine;
+      for (size_t g = 0; g < b.groups.size(); ++g)
+        if (b.group_time[g] >= shard_lo && b.group_time[g] < shard_hi) mine.push_back(b.groups[g]);
+      b.my_groups.swap(mine);
+    }
+  }
+  update_dvs = block_dv;
+  finalized = true;
+}
+
+}  // namespace mc

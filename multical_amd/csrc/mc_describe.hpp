@@ -1,0 +1,148 @@
+// mc_describe.hpp -- validation + recording of error-term batches (host only, no HIP).
+// Mirrors what the Python front-end feeds to problem.addErrorTerm one term at a time
+// (sensors_and_targets.py:274-305, 556-630, 1133-1246; CameraCalibrator.py:195-219).
+#pragma once
+#include "mc_core.hpp"
+
+namespace mc {
+
+inline void requireOpen(const Problem& P) {
+  if (P.finalized) throw std::logic_error("the problem structure is frozen after mc_finalize");
+}
+inline void checkMest(int kind) {
+  if (kind < 0 || kind > 5) throw std::invalid_argument("unknown M-estimator kind");
+}
+
+inline void describeReprojection(Problem& P, int cam, int spline, int dv_q_cb, int dv_t_cb, int dv_toff, int n_obs,
+                                 const double* obs_time, const int* obs_q, const int* obs_t, const int* obs_first,
+                                 const double* y, const double* p, const double* sinv, double pad, int mest, double mest_a) {
+  requireOpen(P);
+  if (cam < 0 || cam >= (int)P.cams.size()) throw std::invalid_argument("camera id out of range");
+  P.checkSpline(spline, 6);
+  P.checkDv(dv_q_cb, DV_ROTATION_QUATERNION); P.checkDv(dv_t_cb, DV_EUCLIDEAN_POINT);
+  if (dv_toff >= 0) P.checkDv(dv_toff, DV_SCALAR);
+  checkMest(mest);
+  if (n_obs < 0 || obs_first[0] != 0) throw std::invalid_argument("obs_first must start at 0");
+  Batch b;
+  b.kind = KIND_REPROJ; b.dim = 2; b.cam = cam; b.spline = spline;
+  b.dv[0] = dv_q_cb; b.dv[1] = dv_t_cb; b.dv[2] = dv_toff;
+  b.pad = pad; b.mest = mest; b.mest_a = mest_a;
+  for (int o = 0; o < n_obs; ++o) {
+    if (obs_first[o + 1] < obs_first[o]) throw std::invalid_argument("obs_first must be nondecreasing");
+    P.checkDv(obs_q[o], DV_ROTATION_QUATERNION); P.checkDv(obs_t[o], DV_EUCLIDEAN_POINT);
+  }
+  int n = obs_first[n_obs];
+  b.n_terms = n;
+  b.t.assign(obs_time, obs_time + n_obs);
+  b.obs_dv_q.assign(obs_q, obs_q + n_obs); b.obs_dv_t.assign(obs_t, obs_t + n_obs);
+  b.obs_first.assign(obs_first, obs_first + n_obs + 1);
+  b.y.assign(y, y + 2 * (size_t)n); b.p.assign(p, p + 3 * (size_t)n); b.sinv.assign(sinv, sinv + n);
+  P.batches.push_back(std::move(b));
+}
+
+inline void describeStaticReprojection(Problem& P, int cam, int n_chain, const int* chain_q, const int* chain_t, int n_obs,
+                                       const int* obs_q, const int* obs_t, const int* obs_first, const double* y,
+                                       const double* p, const double* sinv, int mest, double mest_a) {
+  requireOpen(P);
+  if (cam < 0 || cam >= (int)P.cams.size()) throw std::invalid_argument("camera id out of range");
+  if (n_chain < 0 || n_chain > F2_MAX_CHAIN) throw std::invalid_argument("baseline chain longer than 4 links");
+  checkMest(mest);
+  if (n_obs < 0 || obs_first[0] != 0) throw std::invalid_argument("obs_first must start at 0");
+  Batch b;
+  b.kind = KIND_STATIC_REPROJ; b.dim = 2; b.cam = cam; b.mest = mest; b.mest_a = mest_a;
+  for (int j = 0; j < n_chain; ++j) {
+    P.checkDv(chain_q[j], DV_ROTATION_QUATERNION); P.checkDv(chain_t[j], DV_EUCLIDEAN_POINT);
+    b.chain_q.push_back(chain_q[j]); b.chain_t.push_back(chain_t[j]);
+  }
+  int n = obs_first[n_obs];
+  b.n_terms = n;
+  b.term_obs.resize(n);
+  for (int o = 0; o < n_obs; ++o) {
+    if (obs_first[o + 1] < obs_first[o]) throw std::invalid_argument("obs_first must be nondecreasing");
+    P.checkDv(obs_q[o], DV_ROTATION_QUATERNION); P.checkDv(obs_t[o], DV_EUCLIDEAN_POINT);
+    for (int k = obs_first[o]; k < obs_first[o + 1]; ++k) b.term_obs[k] = o;
+  }
+  b.obs_dv_q.assign(obs_q, obs_q + n_obs); b.obs_dv_t.assign(obs_t, obs_t + n_obs);
+  b.obs_first.assign(obs_first, obs_first + n_obs + 1);
+  b.y.assign(y, y + 2 * (size_t)n); b.p.assign(p, p + 3 * (size_t)n); b.sinv.assign(sinv, sinv + n);
+  P.batches.push_back(std::move(b));
+}
+
+inline void describeImu(Problem& P, bool accel, int pose_spline, int bias_spline, int dv_bias, int dv_g, int dv_q_ib, int dv_r_b,
+                        int n, const double* t, const double* meas, const double* sinv, int mest, double mest_a) {
+  requireOpen(P);
+  P.checkSpline(pose_spline, 6);
+  if (bias_spline >= 0) P.checkSpline(bias_spline, 3);
+  else P.checkDv(dv_bias, DV_EUCLIDEAN_POINT);
+  P.checkDv(dv_q_ib, DV_ROTATION_QUATERNION);
+  if (accel) {
+    P.checkDv(dv_g, -1);
+    if (P.dvs[dv_g].kind != DV_EUCLIDEAN_DIRECTION && P.dvs[dv_g].kind != DV_EUCLIDEAN_POINT)
+      throw std::invalid_argument("gravity must be an EuclideanDirection or an EuclideanPoint");
+    P.checkDv(dv_r_b, DV_EUCLIDEAN_POINT);
+  }
+  checkMest(mest);
+  Batch b;
+  b.kind = accel ? KIND_ACCEL : KIND_GYRO; b.dim = 3; b.spline = pose_spline; b.bias_spline = bias_spline;
+  b.dv[0] = bias_spline >= 0 ? -1 : dv_bias; b.dv[1] = accel ? dv_g : -1; b.dv[2] = dv_q_ib; b.dv[3] = accel ? dv_r_b : -1;
+  b.mest = mest; b.mest_a = mest_a; b.n_terms = n;
+  b.t.assign(t, t + n); b.meas.assign(meas, meas + 3 * (size_t)n); b.sinv.assign(sinv, sinv + n);
+  P.batches.push_back(std::move(b));
+}
+
+inline void describeLidar(Problem& P, int spline, int dv_toff, int dv_q_lb, int dv_t_lb, int n, const double* t,
+                          const double* dir, const double* range, const double* sinv, const int* dv_q_pw, const int* dv_t_pw,
+                          double pad, int mest, double mest_a) {
+  requireOpen(P);
+  P.checkSpline(spline, 6);
+  P.checkDv(dv_q_lb, DV_ROTATION_QUATERNION); P.checkDv(dv_t_lb, DV_EUCLIDEAN_POINT);
+  if (dv_toff >= 0) P.checkDv(dv_toff, DV_SCALAR);
+  checkMest(mest);
+  Batch b;
+  b.kind = KIND_LIDAR; b.dim = 1; b.spline = spline;
+  b.dv[0] = dv_q_lb; b.dv[1] = dv_t_lb; b.dv[2] = dv_toff;
+  b.pad = pad; b.mest = mest; b.mest_a = mest_a; b.n_terms = n;
+  for (int k = 0; k < n; ++k) { P.checkDv(dv_q_pw[k], DV_ROTATION_QUATERNION); P.checkDv(dv_t_pw[k], DV_EUCLIDEAN_POINT); }
+  b.t.assign(t, t + n); b.p.assign(dir, dir + 3 * (size_t)n); b.range.assign(range, range + n); b.sinv.assign(sinv, sinv + n);
+  b.term_dv_q.assign(dv_q_pw, dv_q_pw + n); b.term_dv_t.assign(dv_t_pw, dv_t_pw + n);
+  P.batches.push_back(std::move(b));
+}
+
+// BSplineMotionError: Q = sum_seg M^T (W (x) V^(d)) M scattered into (seg+i, seg+j) blocks
+// (BSP/src/BSpline.cpp:1276-1302, 1483-1548, 1585-1622).  Because M only mixes the S basis functions, block
+// (i, j) of a segment's Q equals  (B^T V_d B)(i, j) * W  with B the segment's S x S basis matrix.
+inline void describeMotion(Problem& P, int spline, const double* W, int order) {
+  requireOpen(P);
+  if (spline < 0 || spline >= (int)P.splines.size()) throw std::invalid_argument("spline id out of range");
+  const SplineRec& s = P.splines[spline];
+  int S = s.order, D = s.dim;
+  if (S <= order && S >= 2) order = S - 1;
+  if (order < 0) throw std::invalid_argument("negative error term order");
+  for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c)
+    if (std::fabs(W[r * D + c] - W[c * D + r]) > 1e-14) throw std::invalid_argument("W must be symmetric");
+  Batch b;
+  b.kind = KIND_MOTION; b.dim = 1; b.n_terms = 1; b.spline = spline; b.motion_order = order;
+  b.Qband.assign((size_t)s.n_coeff * S * D * D, 0.0);
+  std::vector<double> V((size_t)S * S), Dm((size_t)S * S), T((size_t)S * S), q((size_t)S * S);
+  for (int seg = 0; seg < s.n_seg; ++seg) {
+    double dt = P.knots[s.knots_off + S + seg] - P.knots[s.knots_off + S + seg - 1];
+    double recip = dt > 0 ? 1.0 / dt : 0.0;
+    for (int r = 0; r < S; ++r) for (int c = 0; c < S; ++c) { V[r * S + c] = dt / (r + c + 1.0); Dm[r * S + c] = 0.0; }
+    for (int i = 0; i < S - 1; ++i) Dm[i * S + i + 1] = (i + 1.0) * recip;
+    for (int it = 0; it < order; ++it) {  // V <- Dm^T V Dm
+      for (int r = 0; r < S; ++r) for (int c = 0; c < S; ++c) { double a = 0; for (int k = 0; k < S; ++k) a += Dm[k * S + r] * V[k * S + c]; T[r * S + c] = a; }
+      for (int r = 0; r < S; ++r) for (int c = 0; c < S; ++c) { double a = 0; for (int k = 0; k < S; ++k) a += T[r * S + k] * Dm[k * S + c]; V[r * S + c] = a; }
+    }
+    const double* B = &P.basis[s.basis_off + (size_t)seg * S * S];
+    for (int r = 0; r < S; ++r) for (int c = 0; c < S; ++c) { double a = 0; for (int k = 0; k < S; ++k) a += V[r * S + k] * B[k * S + c]; T[r * S + c] = a; }
+    for (int r = 0; r < S; ++r) for (int c = 0; c < S; ++c) { double a = 0; for (int k = 0; k < S; ++k) a += B[k * S + r] * T[k * S + c]; q[r * S + c] = a; }
+    for (int i = 0; i < S; ++i)
+      for (int j = 0; j <= i; ++j) {  // lower band: Q(seg+i, seg+j), offset d = i - j
+        double* blk = &b.Qband[((size_t)(seg + i) * S + (i - j)) * D * D];
+        for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) blk[r * D + c] += q[i * S + j] * W[r * D + c];
+      }
+  }
+  P.batches.push_back(std::move(b));
+}
+
+}  // namespace mc

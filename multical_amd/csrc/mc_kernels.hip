@@ -1,0 +1,811 @@
+// mc_kernels.hip -- gfx950 kernels for LinearSystemSolver::evaluateError and
+// BlockCholeskyLinearSystemSolver::buildSystem (aslam_backend/src/LinearSystemSolver.cpp:12-92,
+// BlockCholeskyLinearSystemSolver.cpp:58-72) plus the state update, and the C ABI of include/multical_hip.h.
+//
+// Execution shape (DESIGN.md has the numbers): one 64-lane wavefront per *group* of error terms that write
+// the same Hessian blocks.  Lanes evaluate one term each (closed forms of mc_terms.h, all in registers),
+// park the weighted Jacobian rows in an LDS tile whose columns follow the group's sorted block order, reduce
+// J^T J for the whole group out of LDS, and only then touch HBM: one fp64 atomic per distinct Hessian entry
+// of the group, lanes walking down a CCS column so the adds of a wave instruction are contiguous.  The value
+// array the atomics land in *is* the fillCCS(upper) array -- there is no block matrix to convert afterwards.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include "../../include/multical_hip.h"
+#include "mc_describe.hpp"
+
+namespace mc {
+
+#define HIP_CHECK(expr)                                                                          \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+enum { STATUS_TIME_OUT_OF_SPLINE = 1, STATUS_BUFFER_EXCEEDED = 2 };
+
+struct DevCommon {
+  const double* x;
+  const int* fp_data;
+  const int* fp_off;
+  const int* col_h;
+  double* Cx;
+  double* rhs;
+  double* e;        // may be null
+  double* chi2;     // per term raw chi^2 (global term numbering)
+  double* Jpart;    // one partial cost per wave
+  int* status;
+  int useM;
+  int build;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// decoded footprint
+struct FpView {
+  int nb, C, coef_lo, nbuf;
+  const int* rolecol;
+  const int* blocks;   // nb x (block index, local col start, dim, global column base)
+  const int* slots;    // nb(nb+1)/2
+  const int* colblk;   // C
+};
+__device__ __forceinline__ FpView fp_view(const DevCommon& dc, int fp) {
+  const int* d = dc.fp_data + dc.fp_off[fp];
+  FpView v;
+  v.nb = d[0]; v.C = d[1]; v.coef_lo = d[2]; v.nbuf = d[3];
+  v.rolecol = d + 4;
+  v.blocks = d + FP_HDR;
+  v.slots = v.blocks + 4 * v.nb;
+  v.colblk = v.slots + (v.nb * (v.nb + 1)) / 2;
+  return v;
+}
+// value index of Hessian entry (local columns ca <= cb) in the CCS array:
+// slot(ia, ib) + rb * h(ib) + rb (rb + 1) / 2 + ra     (see Problem::finalize for the layout)
+__device__ __forceinline__ int entry_addr(const FpView& f, const int* col_h, int ca, int cb) {
+  int ia = f.colblk[ca], ib = f.colblk[cb];
+  int ra = ca - f.blocks[4 * ia + 1], rb = cb - f.blocks[4 * ib + 1];
+  int h = col_h[f.blocks[4 * ib]];
+  return f.slots[(ib * (ib + 1)) / 2 + ia] + rb * h + (rb * (rb + 1)) / 2 + ra;
+}
+__device__ __forceinline__ int global_col(const FpView& f, int ca) {
+  int ia = f.colblk[ca];
+  return f.blocks[4 * ia + 3] + (ca - f.blocks[4 * ia + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// F1: one wave per image observation.  Every corner of the image shares the spline sample, so the
+// per-corner work is a 2 x 19 "core" row pair; the wave reduces the 20 x 20 core Gram matrix (column 19 is
+// the weighted residual) and expands it to the 6 live coefficient blocks with the basis weights.
+enum { F1_LD = F1_CORE + 2 };  // 21: odd stride, conflict-free column reads
+__global__ __launch_bounds__(64) void k_reproj(ReprojBatchView b, DevCommon dc, const GroupRec* __restrict__ groups,
+                                               int jpart_base) {
+  __shared__ double rows[128 * F1_LD];
+  __shared__ double Msh[210];
+  __shared__ int glc[13], gk[13];
+  __shared__ int nglob;
+  const int lane = threadIdx.x;
+  const GroupRec gr = groups[blockIdx.x];
+  F1Common cm;
+  f1_common(b, dc.x, gr.aux, cm);
+  if (!cm.ok) {
+    if (lane == 0) { atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
+    return;
+  }
+  FpView f = fp_view(dc, gr.fp);
+  const int rc0 = f.rolecol[F1_ROLE_COEF];
+  int coef_shift = 0;
+  if (rc0 >= 0) {
+    // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
+    coef_shift = cm.ps.seg - f.coef_lo;
+    if (coef_shift < 0 || coef_shift + S6 > f.nbuf) {
+      if (lane == 0) { atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
+      return;
+    }
+  }
+  double Jacc = 0.0;
+  double macc[4] = {0.0, 0.0, 0.0, 0.0};
+  int ea[4], eb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // entry idx -> (a <= b) of the 20 x 20 upper triangle, idx = b(b+1)/2 + a
+    int idx = lane + 64 * q;
+    int bb = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+    while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
+    while (bb * (bb + 1) / 2 > idx) --bb;
+    ea[q] = idx - bb * (bb + 1) / 2; eb[q] = bb;
+  }
+  for (int base = 0; base < gr.term_count; base += 64) {
+    const int k = base + lane;
+    const int nk = min(64, gr.term_count - base);
+    if (k < gr.term_count) {
+      double core[2 * F1_CORE], e[2];
+      TermOut out;
+      const int term = gr.term_first + k;
+      f1_term(b, dc.x, cm, term, dc.useM != 0, dc.build != 0, core, e, out);
+      Jacc += out.w * out.chi2;
+      dc.chi2[b.term_base_global + term] = out.chi2;
+      if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
+      if (dc.build) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double* row = rows + (2 * lane + r) * F1_LD;
+#pragma unroll
+          for (int c = 0; c < F1_CORE; ++c) row[c] = core[r * F1_CORE + c];
+          row[F1_CORE] = e[r];
+        }
+      }
+    }
+    if (dc.build) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (lane + 64 * q < 210) {
+          double s = 0.0;
+          for (int r = 0; r < 2 * nk; ++r) s += rows[r * F1_LD + ea[q]] * rows[r * F1_LD + eb[q]];
+          macc[q] += s;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  Jacc = wave_sum(Jacc);
+  if (lane == 0) dc.Jpart[jpart_base + blockIdx.x] = Jacc;
+  if (!dc.build) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) if (lane + 64 * q < 210) Msh[lane + 64 * q] = macc[q];
+  if (lane == 0) {
+    int n = 0;
+    for (int g = 0; g < 4; ++g)
+      if (f.rolecol[1 + g] >= 0) for (int d = 0; d < 3; ++d) { glc[n] = f.rolecol[1 + g] + d; gk[n] = 6 + 3 * g + d; ++n; }
+    if (f.rolecol[F1_ROLE_TOFF] >= 0) { glc[n] = f.rolecol[F1_ROLE_TOFF]; gk[n] = 18; ++n; }
+    nglob = n;
+  }
+  __syncthreads();
+  const int ncoef = rc0 >= 0 ? 36 : 0;
+  const int nlive = ncoef + nglob;
+  const int npair = nlive * (nlive + 1) / 2;
+  for (int idx = lane; idx < npair; idx += 64) {
+    int q = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+    while ((q + 1) * (q + 2) / 2 <= idx) ++q;
+    while (q * (q + 1) / 2 > idx) --q;
+    int p = idx - q * (q + 1) / 2;
+    int lcp, kp_, lcq, kq_;
+    double wp, wq;
+    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.ps.w[0][i]; }
+    else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
+    if (q < ncoef) { int i = q / 6; kq_ = q - 6 * i; lcq = rc0 + 6 * (coef_shift + i) + kq_; wq = cm.ps.w[0][i]; }
+    else { lcq = glc[q - ncoef]; kq_ = gk[q - ncoef]; wq = 1.0; }
+    int ka = min(kp_, kq_), kb = max(kp_, kq_);
+    double v = wp * wq * Msh[kb * (kb + 1) / 2 + ka];
+    int ca = min(lcp, lcq), cb = max(lcp, lcq);
+    atomic_add_f64(dc.Cx + entry_addr(f, dc.col_h, ca, cb), v);
+  }
+  for (int p = lane; p < nlive; p += 64) {
+    int lcp, kp_;
+    double wp;
+    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.ps.w[0][i]; }
+    else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
+    atomic_add_f64(dc.rhs + global_col(f, lcp), -wp * Msh[19 * 20 / 2 + kp_]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic group kernel: lanes 0..count-1 evaluate one term each into an LDS row tile (D rows per term,
+// C+1 columns, the last one the weighted residual); the wave then forms the group's J^T J / J^T e.
+template <class View> struct TermTraits;
+template <> struct TermTraits<ImuBatchView> {
+  enum { D = 3 };
+  static __device__ __forceinline__ bool eval(const ImuBatchView& b, const double* x, int k, bool useM, bool wantJ,
+                                              const FpView& f, double* J, int ld, double* e, TermOut& out, int* st) {
+    bool ok = imu_term(b, x, k, useM, wantJ, f.rolecol, J, ld, e, out);
+    if (!ok) *st = STATUS_TIME_OUT_OF_SPLINE;
+    return ok;
+  }
+};
+template <> struct TermTraits<StaticReprojBatchView> {
+  enum { D = 2 };
+  static __device__ __forceinline__ bool eval(const StaticReprojBatchView& b, const double* x, int k, bool useM, bool wantJ,
+                                              const FpView& f, double* J, int ld, double* e, TermOut& out, int*) {
+    return f2_term(b, x, k, useM, wantJ, f.rolecol, J, ld, e, out);
+  }
+};
+template <> struct TermTraits<LidarBatchView> {
+  enum { D = 1 };
+  static __device__ __forceinline__ bool eval(const LidarBatchView& b, const double* x, int k, bool useM, bool wantJ,
+                                              const FpView& f, double* J, int ld, double* e, TermOut& out, int* st) {
+    // place the live coefficient window inside the frozen buffer; the term writes at rolecol[0] + 6*(seg - lo)
+    int rc[MC_MAX_ROLES];
+#pragma unroll
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = f.rolecol[r];
+    if (rc[F5_ROLE_COEF] >= 0) {
+      double t = b.t[k] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
+      if (!(t >= b.sp.t_min && t <= b.sp.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return false; }
+      int seg = spline_segment(b.sp, t);
+      int shift = seg - f.coef_lo;
+      int c0 = rc[F5_ROLE_COEF] + 6 * shift;
+      if (shift < 0 || shift + S6 > f.nbuf) { *st = STATUS_BUFFER_EXCEEDED; return false; }
+      rc[F5_ROLE_COEF] = c0;
+    }
+    bool ok = f5_term(b, x, k, useM, wantJ, rc, J, ld, e, out);
+    if (!ok) *st = STATUS_TIME_OUT_OF_SPLINE;
+    return ok;
+  }
+};
+
+template <class View>
+__global__ __launch_bounds__(64) void k_group(View b, DevCommon dc, const GroupRec* __restrict__ groups, int jpart_base) {
+  extern __shared__ double tile[];
+  constexpr int D = TermTraits<View>::D;
+  const int lane = threadIdx.x;
+  const GroupRec gr = groups[blockIdx.x];
+  FpView f = fp_view(dc, gr.fp);
+  const int C = f.C;
+  const int ld = (C + 1) | 1;
+  const int R = gr.term_count * D;
+  if (dc.build) {
+    for (int i = lane; i < R * ld; i += 64) tile[i] = 0.0;
+    __syncthreads();
+  }
+  double Jacc = 0.0;
+  if (lane < gr.term_count) {
+    const int term = gr.term_first + lane;
+    double e[D];
+    TermOut out;
+    int st = 0;
+    double* Jrow = tile + (size_t)(lane * D) * ld;
+    bool ok = TermTraits<View>::eval(b, dc.x, term, dc.useM != 0, dc.build != 0, f, Jrow, ld, e, out, &st);
+    if (ok) {
+      Jacc = out.w * out.chi2;
+      dc.chi2[b.term_base_global + term] = out.chi2;
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        if (dc.e) dc.e[b.row_base + D * term + r] = -e[r];
+        if (dc.build) Jrow[r * ld + C] = e[r];
+      }
+    } else {
+      atomicOr(dc.status, st);
+    }
+  }
+  Jacc = wave_sum(Jacc);
+  if (lane == 0) dc.Jpart[jpart_base + blockIdx.x] = Jacc;
+  if (!dc.build) return;
+  __syncthreads();
+  for (int cb = 0; cb < C; ++cb) {
+    for (int ca = lane; ca <= cb; ca += 64) {
+      double s = 0.0;
+      for (int r = 0; r < R; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
+      if (s != 0.0) atomic_add_f64(dc.Cx + entry_addr(f, dc.col_h, ca, cb), s);
+    }
+  }
+  for (int ca = lane; ca < C; ca += 64) {
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += tile[r * ld + ca] * tile[r * ld + C];
+    if (s != 0.0) atomic_add_f64(dc.rhs + global_col(f, ca), -s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BSplineMotionError (BSplineMotionError.hpp:62-77, 93-166): one lane per spline coefficient.
+struct MotionView {
+  const double* Qband;   // n_coeff x S x (D x D), Q(i, i - d) row-major
+  const int* slot;       // n_coeff x S: value offset of block (i-d, i) or -1
+  int n_coeff, S, D, param_off, first_block, first_col;
+  int row;               // row of this term in e
+  int term;              // global term index
+};
+__global__ __launch_bounds__(256) void k_motion(MotionView m, DevCommon dc, int jpart_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int D = m.D, S = m.S;
+  double part = 0.0;
+  if (i < m.n_coeff) {
+    const double* c = dc.x + m.param_off;
+    double qc[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < S; ++d) {
+      int j = i - d;
+      if (j >= 0) {  // Q(i, j)
+        const double* Q = m.Qband + ((size_t)i * S + d) * D * D;
+        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) qc[r] += Q[r * D + cc] * c[j * D + cc];
+      }
+      int jj = i + d;
+      if (d > 0 && jj < m.n_coeff) {  // Q(i, jj) = Q(jj, i)^T
+        const double* Q = m.Qband + ((size_t)jj * S + d) * D * D;
+        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) qc[r] += Q[cc * D + r] * c[jj * D + cc];
+      }
+    }
+    for (int r = 0; r < D; ++r) part += c[i * D + r] * qc[r];
+    if (dc.build && m.first_block >= 0) {
+      int h = dc.col_h[m.first_block + i];
+      for (int r = 0; r < D; ++r) atomic_add_f64(dc.rhs + m.first_col + i * D + r, -qc[r]);
+      for (int d = 0; d < S && i - d >= 0; ++d) {
+        const double* Q = m.Qband + ((size_t)i * S + d) * D * D;
+        int base = m.slot[i * S + d];
+        for (int cc = 0; cc < D; ++cc)
+          for (int r = 0; r < (d == 0 ? cc + 1 : D); ++r)
+            atomic_add_f64(dc.Cx + base + cc * h + (cc * (cc + 1)) / 2 + r, Q[r * D + cc]);
+      }
+    }
+  }
+  // block reduction of c^T Q c
+  __shared__ double red[4];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = red[0] + red[1] + red[2] + red[3];
+    dc.Jpart[jpart_base + blockIdx.x] = s;
+  }
+  if (i == 0) { if (dc.e) dc.e[m.row] = 0.0; }
+}
+// chi^2 of a motion term = sum of its partials (raw squared error, BSplineMotionError.hpp:76)
+__global__ void k_motion_chi2(const double* Jpart, int base, int n, double* chi2, int term) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += Jpart[base + i];
+    chi2[term] = s;
+  }
+}
+
+// deterministic final reduction of the per-wave partial costs
+__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ part, int n, double* out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+// Optimizer2::applyStateUpdate (Optimizer2.cpp:292-309) + every DesignVariable::updateImplementation
+struct UpdRec { int kind, dim, off, col; double scaling; };
+__global__ __launch_bounds__(256) void k_update(const UpdRec* __restrict__ recs, int n, const double* __restrict__ dx, double* x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  UpdRec u = recs[i];
+  const double* d = dx + u.col;
+  double* p = x + u.off;
+  if (u.kind == DV_ROTATION_QUATERNION) {
+    double dq[3] = {d[0] * u.scaling, d[1] * u.scaling, d[2] * u.scaling};
+    double q[4] = {p[0], p[1], p[2], p[3]}, o[4];
+    update_quat(q, dq, o);
+    p[0] = o[0]; p[1] = o[1]; p[2] = o[2]; p[3] = o[3];
+  } else if (u.kind == DV_EUCLIDEAN_DIRECTION) {
+    // C <- C * R_ypr(0, dp0, dp1)^T   (ABE/src/EuclideanDirection.cpp:33-38)
+    double R[9], C[9], O[9];
+    ypr0_to_r(d[0] * u.scaling, d[1] * u.scaling, R);
+    for (int k = 0; k < 9; ++k) C[k] = p[k];
+    m3_mult(C, R, O);
+    for (int k = 0; k < 9; ++k) p[k] = O[k];
+  } else {
+    for (int k = 0; k < u.dim; ++k) p[k] += d[k] * u.scaling;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void upload(const std::vector<T>& h) {
+    release();
+    n = h.size();
+    if (n == 0) return;
+    HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
+    HIP_CHECK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (n == 0) return;
+    HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
+    HIP_CHECK(hipMemset(p, 0, n * sizeof(T)));
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  ~DevBuf() { release(); }
+};
+
+struct DevBatch {
+  DevBuf<double> t, y, p, sinv, meas, range, Qband;
+  DevBuf<int> obs_first, obs_q_off, obs_t_off, term_q_off, term_t_off, term_obs, slot;
+  DevBuf<GroupRec> groups;
+  int n_groups = 0, jpart_base = 0, n_jpart = 0, lds_bytes = 0;
+  ReprojBatchView rv; LidarBatchView lv; ImuBatchView iv; StaticReprojBatchView sv; MotionView mv;
+};
+
+}  // namespace mc
+
+using namespace mc;
+
+struct mc_context {
+  Problem P;
+  std::string err;
+  int device = 0;
+  DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, J, dx;
+  DevBuf<int> fp_data, fp_off, col_h, status;
+  DevBuf<UpdRec> upd;
+  std::vector<std::unique_ptr<DevBatch>> db;
+  int n_jpart = 0;
+  bool have_prev = false;
+
+  void uploadStructure();
+  void launchAll(bool build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st);
+};
+
+static thread_local std::string g_create_error;
+
+void mc_context::uploadStructure() {
+  HIP_CHECK(hipSetDevice(device));
+  x.upload(P.x);
+  x_prev.alloc(P.x.size());
+  knots.upload(P.knots);
+  basis.upload(P.basis);
+  fp_data.upload(P.fp_data);
+  fp_off.upload(P.fp_off);
+  col_h.upload(P.col_h);
+  status.alloc(1);
+  Cx.alloc(P.nnz); rhs.alloc(P.j_cols); e.alloc(P.j_rows); chi2.alloc(P.n_terms); J.alloc(1); dx.alloc(P.j_cols);
+  std::vector<UpdRec> ur;
+  for (int dv : P.update_dvs) { const DvRec& d = P.dvs[dv]; ur.push_back(UpdRec{d.kind, d.dim, d.off, d.col, d.scaling}); }
+  upd.upload(ur);
+  n_jpart = 0;
+  db.clear();
+  int term_base = 0;
+  for (Batch& b : P.batches) {
+    std::unique_ptr<DevBatch> d(new DevBatch());
+    auto offs = [&](const std::vector<int>& ids) { std::vector<int> o(ids.size()); for (size_t i = 0; i < ids.size(); ++i) o[i] = P.dvs[ids[i]].off; return o; };
+    d->jpart_base = n_jpart;
+    if (b.kind != KIND_MOTION) {
+      std::vector<GroupRec> mine;
+      for (const GroupRec& g : b.my_groups) if (g.term_count > 0) mine.push_back(g);
+      d->groups.upload(mine);
+      d->n_groups = (int)mine.size();
+      d->n_jpart = d->n_groups;
+      int maxR = 0, maxC = 0;
+      for (const GroupRec& g : mine) { maxR = std::max(maxR, g.term_count * b.dim); maxC = std::max(maxC, P.fp_data[P.fp_off[g.fp] + 1]); }
+      d->lds_bytes = maxR * ((maxC + 1) | 1) * (int)sizeof(double);
+      if (b.kind != KIND_REPROJ && d->lds_bytes > 64 * 1024) throw std::runtime_error("group tile exceeds the LDS budget");
+    }
+    d->sinv.upload(b.sinv);
+    if (b.kind == KIND_REPROJ) {
+      d->t.upload(b.t); d->y.upload(b.y); d->p.upload(b.p);
+      d->obs_first.upload(b.obs_first); d->obs_q_off.upload(offs(b.obs_dv_q)); d->obs_t_off.upload(offs(b.obs_dv_t));
+      ReprojBatchView& v = d->rv;
+      v.cam = P.cameraView(b.cam);
+      v.sp = P.splineView(b.spline, knots.p, basis.p);
+      v.q_cb = P.dvRef(b.dv[0]); v.t_cb = P.dvRef(b.dv[1]); v.toff = P.dvRef(b.dv[2]);
+      v.coef_scale = 1.0; v.qpw_scale = 1.0; v.tpw_scale = 1.0;
+      if (!b.obs_dv_q.empty()) { v.qpw_scale = P.dvs[b.obs_dv_q[0]].scaling; v.tpw_scale = P.dvs[b.obs_dv_t[0]].scaling; }
+      v.obs_time = d->t.p; v.obs_first = d->obs_first.p; v.obs_qpw_off = d->obs_q_off.p; v.obs_tpw_off = d->obs_t_off.p;
+      v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p;
+      v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
+      v.row_base = b.row_base; v.term_base_global = term_base;
+    } else if (b.kind == KIND_LIDAR) {
+      d->t.upload(b.t); d->p.upload(b.p); d->range.upload(b.range);
+      d->term_q_off.upload(offs(b.term_dv_q)); d->term_t_off.upload(offs(b.term_dv_t));
+      LidarBatchView& v = d->lv;
+      v.sp = P.splineView(b.spline, knots.p, basis.p);
+      v.q_lb = P.dvRef(b.dv[0]); v.t_lb = P.dvRef(b.dv[1]); v.toff = P.dvRef(b.dv[2]);
+      v.coef_scale = 1.0; v.qpw_scale = 1.0; v.tpw_scale = 1.0;
+      if (!b.term_dv_q.empty()) { v.qpw_scale = P.dvs[b.term_dv_q[0]].scaling; v.tpw_scale = P.dvs[b.term_dv_t[0]].scaling; }
+      v.t = d->t.p; v.dir = d->p.p; v.range = d->range.p; v.sinv = d->sinv.p; v.qpw_off = d->term_q_off.p; v.tpw_off = d->term_t_off.p;
+      v.mest = b.mest; v.mest_a = b.mest_a; v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
+    } else if (b.kind == KIND_ACCEL || b.kind == KIND_GYRO) {
+      d->t.upload(b.t); d->meas.upload(b.meas);
+      ImuBatchView& v = d->iv;
+      v.pose = P.splineView(b.spline, knots.p, basis.p);
+      v.bias = P.splineView(b.bias_spline, knots.p, basis.p);
+      v.bias_dv = P.dvRef(b.dv[0]); v.g = P.dvRef(b.dv[1]); v.q_ib = P.dvRef(b.dv[2]); v.r_b = P.dvRef(b.dv[3]);
+      v.g_is_direction = (b.dv[1] >= 0 && P.dvs[b.dv[1]].kind == DV_EUCLIDEAN_DIRECTION) ? 1 : 0;
+      v.pose_scale = 1.0; v.bias_scale = b.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
+      v.t = d->t.p; v.meas = d->meas.p; v.sinv = d->sinv.p;
+      v.mest = b.mest; v.mest_a = b.mest_a; v.is_accel = b.kind == KIND_ACCEL ? 1 : 0;
+      v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
+    } else if (b.kind == KIND_STATIC_REPROJ) {
+      d->y.upload(b.y); d->p.upload(b.p);
+      d->obs_first.upload(b.obs_first); d->obs_q_off.upload(offs(b.obs_dv_q)); d->obs_t_off.upload(offs(b.obs_dv_t));
+      d->term_obs.upload(b.term_obs);
+      StaticReprojBatchView& v = d->sv;
+      v.cam = P.cameraView(b.cam);
+      v.n_chain = (int)b.chain_q.size();
+      for (int j = 0; j < v.n_chain; ++j) { v.chain_q[j] = P.dvRef(b.chain_q[j]); v.chain_t[j] = P.dvRef(b.chain_t[j]); }
+      v.qtc_scale = 1.0; v.ttc_scale = 1.0;
+      if (!b.obs_dv_q.empty()) { v.qtc_scale = P.dvs[b.obs_dv_q[0]].scaling; v.ttc_scale = P.dvs[b.obs_dv_t[0]].scaling; }
+      v.proj_scale = P.dvs[P.cams[b.cam].dv_proj].scaling;
+      v.dist_scale = P.cams[b.cam].dv_dist >= 0 ? P.dvs[P.cams[b.cam].dv_dist].scaling : 1.0;
+      v.obs_first = d->obs_first.p; v.obs_qtc_off = d->obs_q_off.p; v.obs_ttc_off = d->obs_t_off.p; v.term_obs = d->term_obs.p;
+      v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p;
+      v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
+      v.row_base = b.row_base; v.term_base_global = term_base;
+    } else {  // KIND_MOTION: handled by rank 0 only (one whole-spline term)
+      const SplineRec& s = P.splines[b.spline];
+      d->Qband.upload(b.Qband);
+      int b0 = P.dvs[s.first_dv].block;
+      std::vector<int> slot((size_t)s.n_coeff * s.order, -1);
+      if (b0 >= 0)
+        for (int i = 0; i < s.n_coeff; ++i)
+          for (int dd = 0; dd < s.order && i - dd >= 0; ++dd) {
+            const std::vector<int>& rows = P.col_rows[b0 + i];
+            size_t k = std::lower_bound(rows.begin(), rows.end(), b0 + i - dd) - rows.begin();
+            slot[(size_t)i * s.order + dd] = P.Cp[P.block_col[b0 + i]] + P.col_roff[b0 + i][k];
+          }
+      d->slot.upload(slot);
+      MotionView& v = d->mv;
+      v.Qband = d->Qband.p; v.slot = d->slot.p; v.n_coeff = s.n_coeff; v.S = s.order; v.D = s.dim;
+      v.param_off = s.param_off; v.first_block = b0; v.first_col = b0 >= 0 ? P.dvs[s.first_dv].col : -1;
+      v.row = b.row_base; v.term = term_base;
+      d->n_groups = P.rank == 0 ? (s.n_coeff + 255) / 256 : 0;
+      d->n_jpart = d->n_groups;
+    }
+    n_jpart += d->n_jpart;
+    term_base += b.n_terms;
+    db.push_back(std::move(d));
+  }
+  Jpart.alloc(std::max(1, n_jpart));
+}
+
+void mc_context::launchAll(bool build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st) {
+  DevCommon dc;
+  dc.x = x.p; dc.fp_data = fp_data.p; dc.fp_off = fp_off.p; dc.col_h = col_h.p;
+  dc.Cx = dCx; dc.rhs = dRhs; dc.e = dE; dc.chi2 = chi2.p; dc.Jpart = Jpart.p; dc.status = status.p;
+  dc.useM = useM; dc.build = build ? 1 : 0;
+  if (build) {
+    HIP_CHECK(hipMemsetAsync(dCx, 0, sizeof(double) * P.nnz, st));
+    HIP_CHECK(hipMemsetAsync(dRhs, 0, sizeof(double) * P.j_cols, st));
+  }
+  if (dE && P.world > 1) HIP_CHECK(hipMemsetAsync(dE, 0, sizeof(double) * P.j_rows, st));
+  for (size_t i = 0; i < db.size(); ++i) {
+    DevBatch& d = *db[i];
+    const Batch& b = P.batches[i];
+    if (d.n_groups == 0) continue;
+    switch (b.kind) {
+      case KIND_REPROJ:
+        hipLaunchKernelGGL(k_reproj, dim3(d.n_groups), dim3(64), 0, st, d.rv, dc, d.groups.p, d.jpart_base);
+        break;
+      case KIND_LIDAR:
+        hipLaunchKernelGGL(k_group<LidarBatchView>, dim3(d.n_groups), dim3(64), d.lds_bytes, st, d.lv, dc, d.groups.p, d.jpart_base);
+        break;
+      case KIND_ACCEL: case KIND_GYRO:
+        hipLaunchKernelGGL(k_group<ImuBatchView>, dim3(d.n_groups), dim3(64), d.lds_bytes, st, d.iv, dc, d.groups.p, d.jpart_base);
+        break;
+      case KIND_STATIC_REPROJ:
+        hipLaunchKernelGGL(k_group<StaticReprojBatchView>, dim3(d.n_groups), dim3(64), d.lds_bytes, st, d.sv, dc, d.groups.p, d.jpart_base);
+        break;
+      case KIND_MOTION:
+        hipLaunchKernelGGL(k_motion, dim3(d.n_groups), dim3(256), 0, st, d.mv, dc, d.jpart_base);
+        hipLaunchKernelGGL(k_motion_chi2, dim3(1), dim3(64), 0, st, Jpart.p, d.jpart_base, d.n_jpart, chi2.p, d.mv.term);
+        break;
+    }
+    HIP_CHECK(hipGetLastError());
+  }
+  if (!build || dJ) {
+    double* out = dJ ? dJ : J.p;
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, Jpart.p, n_jpart, out);
+    HIP_CHECK(hipGetLastError());
+  }
+}
+
+#define MC_TRY try {
+#define MC_CATCH(ctx, rv) } catch (const std::exception& ex) { (ctx)->err = ex.what(); return rv; }
+#define MC_NEED_FINAL(ctx) if (!(ctx)->P.finalized) throw std::logic_error("call mc_finalize first")
+
+extern "C" {
+
+mc_context* mc_create(int device) {
+  try {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) throw std::runtime_error("no HIP device available: the multical_amd backend has no CPU fallback");
+    std::unique_ptr<mc_context> c(new mc_context());
+    if (device < 0) HIP_CHECK(hipGetDevice(&c->device));
+    else { if (device >= n) throw std::runtime_error("device index out of range"); c->device = device; }
+    HIP_CHECK(hipSetDevice(c->device));
+    return c.release();
+  } catch (const std::exception& ex) { g_create_error = ex.what(); return nullptr; }
+}
+void mc_destroy(mc_context* ctx) { delete ctx; }
+const char* mc_last_error(const mc_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mc_add_design_variable(mc_context* ctx, int kind, const double* params, int n_params, int active, double scaling) {
+  MC_TRY requireOpen(ctx->P);
+  if (kind == MC_DV_SPLINE_COEFF) throw std::invalid_argument("spline coefficients are added by mc_add_spline");
+  return ctx->P.addDv(kind, params, n_params, active, scaling);
+  MC_CATCH(ctx, -1)
+}
+int mc_add_spline(mc_context* ctx, int order, int dim, const double* knots, int n_knots, const double* coeffs, int n_coeff, int active) {
+  MC_TRY requireOpen(ctx->P);
+  return ctx->P.addSpline(order, dim, knots, n_knots, coeffs, n_coeff, active);
+  MC_CATCH(ctx, -1)
+}
+int mc_spline_first_dv(const mc_context* ctx, int spline_id) {
+  if (spline_id < 0 || spline_id >= (int)ctx->P.splines.size()) return -1;
+  return ctx->P.splines[spline_id].first_dv;
+}
+int mc_add_camera(mc_context* ctx, int projection_model, int distortion_model, int dv_projection, int dv_distortion) {
+  MC_TRY requireOpen(ctx->P);
+  return ctx->P.addCamera(projection_model, distortion_model, dv_projection, dv_distortion);
+  MC_CATCH(ctx, -1)
+}
+int mc_add_reprojection_batch(mc_context* ctx, int camera, int pose_spline, int dv_q_c_b, int dv_t_c_b, int dv_time_offset,
+                              int n_obs, const double* obs_time, const int* obs_dv_q_p_w, const int* obs_dv_t_p_w,
+                              const int* obs_first, const double* y, const double* p_target, const double* sqrt_inv_r,
+                              double time_padding, int mest_kind, double mest_param) {
+  MC_TRY describeReprojection(ctx->P, camera, pose_spline, dv_q_c_b, dv_t_c_b, dv_time_offset, n_obs, obs_time, obs_dv_q_p_w,
+                              obs_dv_t_p_w, obs_first, y, p_target, sqrt_inv_r, time_padding, mest_kind, mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_static_reprojection_batch(mc_context* ctx, int camera, int n_chain, const int* chain_dv_q, const int* chain_dv_t,
+                                     int n_obs, const int* obs_dv_q_t_c, const int* obs_dv_t_t_c, const int* obs_first,
+                                     const double* y, const double* p_target, const double* sqrt_inv_r, int mest_kind,
+                                     double mest_param) {
+  MC_TRY describeStaticReprojection(ctx->P, camera, n_chain, chain_dv_q, chain_dv_t, n_obs, obs_dv_q_t_c, obs_dv_t_t_c,
+                                    obs_first, y, p_target, sqrt_inv_r, mest_kind, mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_accelerometer_batch(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_gravity, int dv_q_i_b,
+                               int dv_r_b, int n, const double* t, const double* meas, const double* sqrt_inv_r,
+                               int mest_kind, double mest_param) {
+  MC_TRY describeImu(ctx->P, true, pose_spline, bias_spline, dv_bias, dv_gravity, dv_q_i_b, dv_r_b, n, t, meas, sqrt_inv_r,
+                     mest_kind, mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_gyroscope_batch(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_q_i_b, int n, const double* t,
+                           const double* meas, const double* sqrt_inv_r, int mest_kind, double mest_param) {
+  MC_TRY describeImu(ctx->P, false, pose_spline, bias_spline, dv_bias, -1, dv_q_i_b, -1, n, t, meas, sqrt_inv_r, mest_kind,
+                     mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_lidar_batch(mc_context* ctx, int pose_spline, int dv_time_offset, int dv_q_l_b, int dv_t_l_b, int n, const double* t,
+                       const double* dir, const double* range, const double* sqrt_inv_r, const int* dv_q_p_w,
+                       const int* dv_t_p_w, double time_padding, int mest_kind, double mest_param) {
+  MC_TRY describeLidar(ctx->P, pose_spline, dv_time_offset, dv_q_l_b, dv_t_l_b, n, t, dir, range, sqrt_inv_r, dv_q_p_w, dv_t_p_w,
+                       time_padding, mest_kind, mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_motion_term(mc_context* ctx, int spline, const double* W, int error_term_order) {
+  MC_TRY describeMotion(ctx->P, spline, W, error_term_order);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_set_shard(mc_context* ctx, int rank, int world) {
+  MC_TRY requireOpen(ctx->P);
+  if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("need 0 <= rank < world");
+  ctx->P.rank = rank; ctx->P.world = world;
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_finalize(mc_context* ctx) {
+  MC_TRY ctx->P.finalize();
+  ctx->uploadStructure();
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_dims(const mc_context* ctx, int* j_rows, int* j_cols, int* n_blocks, int* n_terms, int* nnz) {
+  if (!ctx->P.finalized) return -1;
+  if (j_rows) *j_rows = ctx->P.j_rows;
+  if (j_cols) *j_cols = ctx->P.j_cols;
+  if (n_blocks) *n_blocks = ctx->P.n_blocks;
+  if (n_terms) *n_terms = ctx->P.n_terms;
+  if (nnz) *nnz = ctx->P.nnz;
+  return 0;
+}
+int mc_dv_block(const mc_context* ctx, int dv, int* block_index, int* column_base) {
+  if (!ctx->P.finalized || dv < 0 || dv >= (int)ctx->P.dvs.size()) return -1;
+  *block_index = ctx->P.dvs[dv].block; *column_base = ctx->P.dvs[dv].col;
+  return 0;
+}
+int mc_get_pattern(const mc_context* ctx, int* Cp, int* Ci) {
+  if (!ctx->P.finalized) return -1;
+  if (Cp) std::memcpy(Cp, ctx->P.Cp.data(), sizeof(int) * ctx->P.Cp.size());
+  if (Ci) std::memcpy(Ci, ctx->P.Ci.data(), sizeof(int) * ctx->P.Ci.size());
+  return 0;
+}
+
+int mc_evaluate_error_device(mc_context* ctx, int use_mestimator, double* d_J, double* d_e, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->launchAll(false, use_mestimator, nullptr, nullptr, d_J, d_e, (hipStream_t)stream);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_build_system_device(mc_context* ctx, int use_mestimator, double* d_Cx, double* d_rhs, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->launchAll(true, use_mestimator, d_Cx, d_rhs, nullptr, nullptr, (hipStream_t)stream);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_evaluate_error(mc_context* ctx, int use_mestimator, double* J_out, double* e_out) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->launchAll(false, use_mestimator, nullptr, nullptr, ctx->J.p, e_out ? ctx->e.p : nullptr, 0);
+  HIP_CHECK(hipStreamSynchronize(0));
+  if (J_out) HIP_CHECK(hipMemcpy(J_out, ctx->J.p, sizeof(double), hipMemcpyDeviceToHost));
+  if (e_out) HIP_CHECK(hipMemcpy(e_out, ctx->e.p, sizeof(double) * ctx->P.j_rows, hipMemcpyDeviceToHost));
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double* rhs_out) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->launchAll(true, use_mestimator, ctx->Cx.p, ctx->rhs.p, nullptr, nullptr, 0);
+  HIP_CHECK(hipStreamSynchronize(0));
+  if (Cx_out) HIP_CHECK(hipMemcpy(Cx_out, ctx->Cx.p, sizeof(double) * ctx->P.nnz, hipMemcpyDeviceToHost));
+  if (rhs_out) HIP_CHECK(hipMemcpy(rhs_out, ctx->rhs.p, sizeof(double) * ctx->P.j_cols, hipMemcpyDeviceToHost));
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_get_term_chi2(mc_context* ctx, double* chi2_out) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpy(chi2_out, ctx->chi2.p, sizeof(double) * ctx->P.n_terms, hipMemcpyDeviceToHost));
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_apply_update(mc_context* ctx, const double* dx) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  HIP_CHECK(hipMemcpyAsync(ctx->x_prev.p, ctx->x.p, sizeof(double) * ctx->P.x.size(), hipMemcpyDeviceToDevice, 0));
+  HIP_CHECK(hipMemcpyAsync(ctx->dx.p, dx, sizeof(double) * ctx->P.j_cols, hipMemcpyHostToDevice, 0));
+  int n = (int)ctx->upd.n;
+  hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, 0, ctx->upd.p, n, ctx->dx.p, ctx->x.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(0));
+  ctx->have_prev = true;
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_revert_update(mc_context* ctx) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  if (!ctx->have_prev) throw std::logic_error("no update to revert");
+  HIP_CHECK(hipSetDevice(ctx->device));
+  HIP_CHECK(hipMemcpy(ctx->x.p, ctx->x_prev.p, sizeof(double) * ctx->P.x.size(), hipMemcpyDeviceToDevice));
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_get_dv_params(mc_context* ctx, int dv, double* out) {
+  MC_TRY
+  if (dv < 0 || dv >= (int)ctx->P.dvs.size()) throw std::invalid_argument("design variable id out of range");
+  const DvRec& d = ctx->P.dvs[dv];
+  if (ctx->P.finalized) {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMemcpy(out, ctx->x.p + d.off, sizeof(double) * d.nparam, hipMemcpyDeviceToHost));
+  } else std::memcpy(out, &ctx->P.x[d.off], sizeof(double) * d.nparam);
+  return d.nparam;
+  MC_CATCH(ctx, -1)
+}
+int mc_device_status(mc_context* ctx) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  int s = 0;
+  HIP_CHECK(hipMemcpy(&s, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (s) HIP_CHECK(hipMemset(ctx->status.p, 0, sizeof(int)));
+  if (s & STATUS_BUFFER_EXCEEDED) ctx->err = "Spline Coefficient Buffer Exceeded. Set larger buffer margins!";
+  else if (s & STATUS_TIME_OUT_OF_SPLINE) ctx->err = "The time is out of range of the spline";
+  return s;
+  MC_CATCH(ctx, -1)
+}
+int mc_device_info(mc_context* ctx, char* name, int name_len, int* n_cu, double* hbm_gib) {
+  MC_TRY
+  hipDeviceProp_t p;
+  HIP_CHECK(hipGetDeviceProperties(&p, ctx->device));
+  if (name && name_len > 0) { std::snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+  if (n_cu) *n_cu = p.multiProcessorCount;
+  if (hbm_gib) *hbm_gib = (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+
+}  // extern "C"

@@ -1,0 +1,563 @@
+// mc_terms.h -- closed-form residual + Jacobian of every Multical error-term kind.
+//
+// The reference evaluates a term by walking an expression DAG twice (value, then reverse chain rule
+// with heap-allocated MatrixXd products: SURVEY.md section 3.5).  Here each kind is lowered once, by
+// hand, into straight-line fp64 code: the chain of boxTimes / boxMinus / cross products collapses into
+// a few 3-vector operations per Jacobian row.  Comments give the DAG the formulas come from.
+//
+// Output convention.  A term writes its weighted Jacobian rows into `J` (row stride `ld`) at column
+// `rolecol[role] + c`; a negative rolecol drops the block (inactive design variable -- what
+// JacobianContainer::add does, aslam_backend/include/aslam/backend/JacobianContainer.hpp:124-126).
+// "Weighted" means  sqrt(w(chi2)) * sqrtInvR^T * J * dv.scaling()  exactly as
+// ErrorTermFs::buildHessianImplementation + JacobianContainer::evaluateHessian apply it
+// (aslam_backend/include/aslam/backend/implementation/ErrorTerm.hpp:96-109, src/JacobianContainer.cpp:151-167).
+// The kernels point `J` at an LDS tile whose columns follow the group's sorted block order; the
+// CPU-side probe used by the tests points it at a dense row of the global Jacobian.
+#pragma once
+#include "mc_math.h"
+
+namespace mc {
+
+enum { MC_MAX_ROLES = 12 };
+constexpr int S6 = 6;  // spline order handled by the kernels (Multical: splineOrder = 6 everywhere)
+
+struct DvRef {
+  int off;      // parameter offset in the state vector (-1: not present)
+  int block;    // block index (-1: inactive)
+  int col;      // column base (-1: inactive)
+  double scale; // DesignVariable::scaling()
+};
+
+struct TermOut {
+  double chi2;   // raw squared error  e^T invR e
+  double w;      // M-estimator weight w(chi2)
+};
+
+// ------------------------------------------------------------------------------------------------
+// pose spline sample shared by the kinds: value, derivatives, rotation, S matrix
+// (BSplinePose::transformation / curveValueToTransformationAndJacobian, BSP/src/BSplinePose.cpp:21-24, 394-412)
+struct PoseSample {
+  double w[3][S6];   // basis weights for derivative 0,1,2
+  double c[6], cd[6], cdd[6];
+  double C[9], S[9];  // C_w_b(theta), S(theta)
+  int seg;
+};
+template <int ND>
+MC_HD bool pose_sample(const SplineView& sp, const double* x, double t, PoseSample& ps) {
+  ps.seg = spline_weights<S6, ND>(sp, t, ps.w);
+  if (ps.seg < 0) return false;
+  const double* cf = x + sp.param_off + (size_t)ps.seg * 6;
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+    for (int i = 0; i < S6; ++i) {
+      double v = cf[i * 6 + d];
+      a0 += v * ps.w[0][i];
+      if (ND > 1) a1 += v * ps.w[1][i];
+      if (ND > 2) a2 += v * ps.w[2][i];
+    }
+    ps.c[d] = a0; ps.cd[d] = a1; ps.cdd[d] = a2;
+  }
+  rotvec_C_S(ps.c + 3, ps.C, ps.S);
+  return true;
+}
+// [u v] * JT,  JT = [I, -r^ S; 0, S]  (BSplinePose.cpp:402-407)  ->  [u, (v - u x r) S]
+MC_HD void chain_JT(const double* u, const double* v, const PoseSample& ps, double* B) {
+  double c[3], wv[3];
+  v3_cross(u, ps.c, c);
+  wv[0] = v[0] - c[0]; wv[1] = v[1] - c[1]; wv[2] = v[2] - c[2];
+  B[0] = u[0]; B[1] = u[1]; B[2] = u[2];
+  m3_tmulv(ps.S, wv, B + 3);
+}
+// TransformationBasic leaves (ABE/src/TransformationBasic.cpp:48-67): chain [u v] ->
+//   translation block = u ;  rotation block = v - u x r
+MC_HD void chain_basic(const double* u, const double* v, const double* r, double* Jq, double* Jt) {
+  double c[3];
+  v3_cross(u, r, c);
+  Jq[0] = v[0] - c[0]; Jq[1] = v[1] - c[1]; Jq[2] = v[2] - c[2];
+  Jt[0] = u[0]; Jt[1] = u[1]; Jt[2] = u[2];
+}
+MC_HD void load_rigid(const double* x, int qoff, int toff, Rigid& T) {
+  quat2r(x + qoff, T.C);
+  T.r[0] = x[toff]; T.r[1] = x[toff + 1]; T.r[2] = x[toff + 2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// F1: SimpleReprojectionError with time-offset pose spline
+//   p_c = T_c_b * inverse(T_w_b(t0 + d)) * inverse(T_p_w) * p      (sensors_and_targets.py:571-611)
+// Core columns (19): [0..5] B = chain into one spline coefficient before the basis weight,
+//                    [6..8] q_c_b, [9..11] t_c_b, [12..14] q_p_w, [15..17] t_p_w, [18] time offset.
+// The Jacobian wrt local spline coefficient i is w_i * B (TransformationTimeOffsetExpressionNode,
+// aslam_splines/src/BSplineExpressions.cpp:495-544) -- every corner of one image shares the w_i, which
+// is what lets the kernel reduce a 19x19 core per image instead of an 85x85 block matrix per corner.
+enum { F1_CORE = 19 };
+enum { F1_ROLE_COEF = 0, F1_ROLE_QCB = 1, F1_ROLE_TCB = 2, F1_ROLE_QPW = 3, F1_ROLE_TPW = 4, F1_ROLE_TOFF = 5 };
+struct ReprojBatchView {
+  CameraView cam;
+  SplineView sp;
+  DvRef q_cb, t_cb, toff;
+  double coef_scale, qpw_scale, tpw_scale;
+  const double* obs_time;
+  const int* obs_first;
+  const int* obs_qpw_off;  // per observation: parameter offsets of the target's q / t
+  const int* obs_tpw_off;
+  const double* y;
+  const double* p;
+  const double* sinv;
+  int mest; double mest_a;
+  int n_obs, n_terms;
+  int row_base;   // row base of term 0 of this batch
+  int term_base_global;  // global index of term 0 of this batch
+};
+struct F1Common {
+  PoseSample ps;
+  Rigid Tcb, Tcp, X;   // T_c_b, T_c_p = X * T_w_p, X = T_c_b * T_b_w
+  double rpw[3];
+  bool ok;
+};
+MC_HD void f1_common(const ReprojBatchView& b, const double* x, int obs, F1Common& cm) {
+  double t = b.obs_time[obs] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
+  cm.ok = pose_sample<2>(b.sp, x, t, cm.ps);
+  if (!cm.ok) return;
+  load_rigid(x, b.q_cb.off, b.t_cb.off, cm.Tcb);
+  Rigid Twb, Tbw, Tpw, Twp;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Twb.C[i] = cm.ps.C[i];
+  Twb.r[0] = cm.ps.c[0]; Twb.r[1] = cm.ps.c[1]; Twb.r[2] = cm.ps.c[2];
+  rigid_inv(Twb, Tbw);
+  load_rigid(x, b.obs_qpw_off[obs], b.obs_tpw_off[obs], Tpw);
+  cm.rpw[0] = Tpw.r[0]; cm.rpw[1] = Tpw.r[1]; cm.rpw[2] = Tpw.r[2];
+  rigid_inv(Tpw, Twp);
+  rigid_mul(cm.Tcb, Tbw, cm.X);
+  rigid_mul(cm.X, Twp, cm.Tcp);
+}
+// One corner: weighted core rows (2 x 19, row-major) and weighted residual e[2].
+MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,
+                   double* core, double* e, TermOut& out) {
+  const double* pt = b.p + 3 * (size_t)k;
+  double pc[3];
+  m3_mulv(cm.Tcp.C, pt, pc);
+  pc[0] += cm.Tcp.r[0]; pc[1] += cm.Tcp.r[1]; pc[2] += cm.Tcp.r[2];
+  double kp[2], Jc[6];
+  project(b.cam.model, b.cam.dist, x + b.cam.proj_off, b.cam.dist_off >= 0 ? x + b.cam.dist_off : x, pc, kp,
+          wantJ ? Jc : nullptr);
+  double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
+  double s = b.sinv[k];
+  out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
+  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
+  double sw = sqrt(out.w) * s;
+  e[0] = sw * e0; e[1] = sw * e1;
+  if (!wantJ) return;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    double* row = core + r * F1_CORE;
+    // A0 = -J_cam; through HomogeneousExpressionNodeMultiply: A1 = A0 * boxMinus(p_c) = [a, a x p_c]
+    double a[3] = {-sw * Jc[3 * r], -sw * Jc[3 * r + 1], -sw * Jc[3 * r + 2]};
+    double ap[3];
+    v3_cross(a, pc, ap);
+    // lhs of (X * T_w_p), lhs of (T_c_b * T_b_w): TransformationBasic(q_c_b, t_c_b)
+    chain_basic(a, ap, cm.Tcb.r, row + 6, row + 9);
+    // rhs T_w_p = inverse(T_p_w): chain * boxTimes(X) * (-boxTimes(T_w_p)) = -chain * boxTimes(T_c_p)
+    double u[3], v[3];
+    chain_boxtimes(a, ap, cm.Tcp, u, v);
+    u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
+    chain_basic(u, v, cm.rpw, row + 12, row + 15);
+    // rhs T_b_w = inverse(T_w_b): chain * boxTimes(T_c_b) * (-boxTimes(T_b_w)) = -chain * boxTimes(X)
+    chain_boxtimes(a, ap, cm.X, u, v);
+    u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
+    chain_JT(u, v, cm.ps, row);
+    // time offset: B * (Phi_dot c)  (BSplineExpressions.cpp:538-541)
+    double jd = 0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) jd += row[d] * cm.ps.cd[d];
+    row[18] = jd * b.toff.scale;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) row[d] *= b.coef_scale;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      row[6 + d] *= b.q_cb.scale; row[9 + d] *= b.t_cb.scale;
+      row[12 + d] *= b.qpw_scale; row[15 + d] *= b.tpw_scale;
+    }
+  }
+}
+// expand one core row into a (sorted / dense) Jacobian row
+MC_HD void f1_expand_row(const double* core, const double* w, const int* rolecol, double* Jrow) {
+  if (rolecol[F1_ROLE_COEF] >= 0)
+    for (int i = 0; i < S6; ++i)
+      for (int d = 0; d < 6; ++d) Jrow[rolecol[F1_ROLE_COEF] + 6 * i + d] = w[i] * core[d];
+  for (int g = 0; g < 4; ++g)
+    if (rolecol[1 + g] >= 0)
+      for (int d = 0; d < 3; ++d) Jrow[rolecol[1 + g] + d] = core[6 + 3 * g + d];
+  if (rolecol[F1_ROLE_TOFF] >= 0) Jrow[rolecol[F1_ROLE_TOFF]] = core[18];
+}
+
+// ------------------------------------------------------------------------------------------------
+// F5: Multical LiDAR point-to-plane ScalarError (sensors_and_targets.py:274-305)
+//   T_p_l = T_p_w * (T_w_b(t + d) * inverse(T_l_b));  pred = -(n . t_p) / (n . C_p_l dir),  n = e_z
+enum { F5_ROLE_COEF = 0, F5_ROLE_QLB = 1, F5_ROLE_TLB = 2, F5_ROLE_QPW = 3, F5_ROLE_TPW = 4, F5_ROLE_TOFF = 5 };
+struct LidarBatchView {
+  SplineView sp;
+  DvRef q_lb, t_lb, toff;
+  double coef_scale, qpw_scale, tpw_scale;
+  const double* t;
+  const double* dir;
+  const double* range;
+  const double* sinv;
+  const int* qpw_off;  // per term
+  const int* tpw_off;
+  int mest; double mest_a;
+  int n_terms, row_base, term_base_global;
+};
+MC_HD bool f5_term(const LidarBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
+                   double* J, int ld, double* e, TermOut& out) {
+  double t = b.t[k] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
+  PoseSample ps;
+  if (!pose_sample<2>(b.sp, x, t, ps)) return false;
+  Rigid Twb, Tlb, Tbl, Tpw, Twl, Tpl;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Twb.C[i] = ps.C[i];
+  Twb.r[0] = ps.c[0]; Twb.r[1] = ps.c[1]; Twb.r[2] = ps.c[2];
+  load_rigid(x, b.q_lb.off, b.t_lb.off, Tlb);
+  rigid_inv(Tlb, Tbl);
+  load_rigid(x, b.qpw_off[k], b.tpw_off[k], Tpw);
+  rigid_mul(Twb, Tbl, Twl);
+  rigid_mul(Tpw, Twl, Tpl);
+  const double* dir = b.dir + 3 * (size_t)k;
+  double Cd[3];
+  m3_mulv(Tpl.C, dir, Cd);
+  double d = Tpl.r[2], th = Cd[2];
+  double pred = (d / th) * -1.0;
+  double e0 = pred - b.range[k];
+  double s = b.sinv[k];
+  out.chi2 = (s * e0) * (s * e0);
+  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
+  double sw = sqrt(out.w) * s;
+  e[0] = sw * e0;
+  if (!wantJ) return true;
+  // scalar chain: Multiply(., -1) -> -1 ; Divide(d, theta): a_d = -1/theta, a_th = d/theta^2
+  double a_d = sw * (-1.0 / th), a_th = sw * (d / (th * th));
+  // chain into T_p_l: a_d n^T [I | t_p^]  +  a_th n^T (C dir)^ [0 | I]       (row x matrix^ = row cross vector)
+  double n[3] = {0.0, 0.0, 1.0};
+  double u[3] = {a_d * n[0], a_d * n[1], a_d * n[2]};
+  double v[3], tmp[3];
+  v3_cross(u, Tpl.r, v);
+  double un[3] = {a_th * n[0], a_th * n[1], a_th * n[2]};
+  v3_cross(un, Cd, tmp);
+  v[0] += tmp[0]; v[1] += tmp[1]; v[2] += tmp[2];
+  double Jq[3], Jt[3];
+  // lhs T_p_w: TransformationBasic(q_p_w, t_p_w)
+  chain_basic(u, v, Tpw.r, Jq, Jt);
+  if (rolecol[F5_ROLE_QPW] >= 0) for (int c = 0; c < 3; ++c) J[rolecol[F5_ROLE_QPW] + c] = Jq[c] * b.qpw_scale;
+  if (rolecol[F5_ROLE_TPW] >= 0) for (int c = 0; c < 3; ++c) J[rolecol[F5_ROLE_TPW] + c] = Jt[c] * b.tpw_scale;
+  // rhs T_w_l: chain * boxTimes(T_p_w)
+  double u2[3], v2[3];
+  chain_boxtimes(u, v, Tpw, u2, v2);
+  // lhs T_w_b: time-offset spline node
+  double B[6];
+  chain_JT(u2, v2, ps, B);
+  if (rolecol[F5_ROLE_COEF] >= 0)
+    for (int i = 0; i < S6; ++i)
+      for (int c = 0; c < 6; ++c) J[rolecol[F5_ROLE_COEF] + 6 * i + c] = ps.w[0][i] * B[c] * b.coef_scale;
+  if (rolecol[F5_ROLE_TOFF] >= 0) {
+    double jd = 0;
+    for (int c = 0; c < 6; ++c) jd += B[c] * ps.cd[c];
+    J[rolecol[F5_ROLE_TOFF]] = jd * b.toff.scale;
+  }
+  // rhs T_b_l = inverse(T_l_b): chain * boxTimes(T_w_b) * (-boxTimes(T_b_l)) = -chain * boxTimes(T_w_l)
+  double u3[3], v3[3];
+  chain_boxtimes(u2, v2, Twl, u3, v3);
+  u3[0] = -u3[0]; u3[1] = -u3[1]; u3[2] = -u3[2]; v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2];
+  chain_basic(u3, v3, Tlb.r, Jq, Jt);
+  if (rolecol[F5_ROLE_QLB] >= 0) for (int c = 0; c < 3; ++c) J[rolecol[F5_ROLE_QLB] + c] = Jq[c] * b.q_lb.scale;
+  if (rolecol[F5_ROLE_TLB] >= 0) for (int c = 0; c < 3; ++c) J[rolecol[F5_ROLE_TLB] + c] = Jt[c] * b.t_lb.scale;
+  (void)ld;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F3 / F4: kalibr EuclideanError, accelerometer and gyroscope forms (sensors_and_targets.py:1152-1170, 1198-1212)
+//   gyro : C_i_b * w_b(t) + b_g(t) - w_meas
+//   accel: C_i_b * (C_b_w(t) (a_w(t) - g_w) + wdot_b(t) x r_b + w_b x (w_b x r_b)) + b_a(t) - a_meas
+// with w_b = -C_b_w S(theta) theta_dot and the reference's "angular acceleration" -C_b_w S(theta) theta_ddot
+// (BSP/src/BSplinePose.cpp:207-253, 288-331: the S_dot theta_dot term is dropped there and here).
+enum { IMU_ROLE_POSE = 0, IMU_ROLE_BIAS = 1, IMU_ROLE_G = 2, IMU_ROLE_QIB = 3, IMU_ROLE_RB = 4 };
+struct ImuBatchView {
+  SplineView pose;
+  SplineView bias;      // order 0 => static bias in dv_bias
+  DvRef bias_dv;
+  DvRef g, q_ib, r_b;
+  int g_is_direction;
+  double pose_scale, bias_scale;
+  const double* t;
+  const double* meas;
+  const double* sinv;
+  int mest; double mest_a;
+  int is_accel;
+  int n_terms, row_base, term_base_global;
+};
+// body-frame rate -C_b_w S v and the two 3x3 factors of its coefficient Jacobian:
+//   d rate / d coef_i (rotation part) = w_i * G0 + wd_i * G1,  G1 = -C_b_w S,
+//   G0 = -C_b_w D(theta, v) - rate^ C_b_w S    (BSplinePose.cpp:243-248 with Jr from :64-83)
+MC_HD void body_rate(const PoseSample& ps, const double* v, double* rate, double* G0, double* G1) {
+  double CbwS[9];
+  m3_tmul(ps.C, ps.S, CbwS);  // C_w_b^T S
+  double t[3];
+  m3_mulv(CbwS, v, t);
+  rate[0] = -t[0]; rate[1] = -t[1]; rate[2] = -t[2];
+  if (!G0) return;
+  double D[9], CD[9], K[9], KC[9];
+  rotvec_dSv_dtheta(ps.c + 3, v, D);
+  m3_tmul(ps.C, D, CD);
+  m3_skew(rate, K);
+  m3_mul(K, CbwS, KC);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { G0[i] = -CD[i] - KC[i]; G1[i] = -CbwS[i]; }
+}
+MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol, double* J,
+                    int ld, double* e, TermOut& out) {
+  double t = b.t[k];
+  PoseSample ps;
+  bool ok = b.is_accel ? pose_sample<3>(b.pose, x, t, ps) : pose_sample<2>(b.pose, x, t, ps);
+  if (!ok) return false;
+  // bias
+  double bw[1][S6];
+  double bias[3];
+  int bseg = 0;
+  if (b.bias.order > 0) {
+    bseg = spline_weights<S6, 1>(b.bias, t, bw);
+    if (bseg < 0) return false;
+    const double* cf = x + b.bias.param_off + (size_t)bseg * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      double a = 0;
+#pragma unroll
+      for (int i = 0; i < S6; ++i) a += cf[3 * i + d] * bw[0][i];
+      bias[d] = a;
+    }
+  } else {
+    bias[0] = x[b.bias_dv.off]; bias[1] = x[b.bias_dv.off + 1]; bias[2] = x[b.bias_dv.off + 2];
+  }
+  double Cib[9];
+  quat2r(x + b.q_ib.off, Cib);
+  double om[3], G0w[9], G1[9];
+  body_rate(ps, ps.cd + 3, om, wantJ ? G0w : nullptr, G1);
+  double inner[3];
+  double al[3], G0a[9], v1[3], rb[3] = {0, 0, 0}, omxr[3];
+  if (b.is_accel) {
+    double G1b[9];
+    body_rate(ps, ps.cdd + 3, al, wantJ ? G0a : nullptr, G1b);
+    double g[3];
+    if (b.g_is_direction) {  // EuclideanDirection::toEuclidean: magnitude * C.col(2)  (state: C row-major 9 + magnitude)
+      const double* Cg = x + b.g.off;
+      g[0] = Cg[9] * Cg[2]; g[1] = Cg[9] * Cg[5]; g[2] = Cg[9] * Cg[8];
+    } else { g[0] = x[b.g.off]; g[1] = x[b.g.off + 1]; g[2] = x[b.g.off + 2]; }
+    double ag[3] = {ps.cdd[0] - g[0], ps.cdd[1] - g[1], ps.cdd[2] - g[2]};
+    m3_tmulv(ps.C, ag, v1);  // C_b_w (a_w - g)
+    rb[0] = x[b.r_b.off]; rb[1] = x[b.r_b.off + 1]; rb[2] = x[b.r_b.off + 2];
+    double alxr[3], oo[3];
+    v3_cross(al, rb, alxr);
+    v3_cross(om, rb, omxr);
+    v3_cross(om, omxr, oo);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) inner[d] = v1[d] + alxr[d] + oo[d];
+  } else {
+    inner[0] = om[0]; inner[1] = om[1]; inner[2] = om[2];
+  }
+  double pr[3];
+  m3_mulv(Cib, inner, pr);
+  double ev[3];
+  const double* m = b.meas + 3 * (size_t)k;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) ev[d] = pr[d] + bias[d] - m[d];
+  double s = b.sinv[k];
+  out.chi2 = (s * s) * (ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
+  double sw = sqrt(out.w) * s;
+  e[0] = sw * ev[0]; e[1] = sw * ev[1]; e[2] = sw * ev[2];
+  if (!wantJ) return true;
+
+  // q_i_b : crossMx(C_i_b * inner)   (EuclideanExpressionNodeMultiply, ABE/src/EuclideanExpressionNode.cpp:82-86)
+  if (rolecol[IMU_ROLE_QIB] >= 0) {
+    double K[9];
+    m3_skew(pr, K);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_QIB] + c] = sw * b.q_ib.scale * K[3 * r + c];
+  }
+  // bias: w^b_i * I  (BSplineEuclideanExpressionNode, BSplineExpressions.cpp:589-599) or I (static EuclideanPoint)
+  if (rolecol[IMU_ROLE_BIAS] >= 0) {
+    if (b.bias.order > 0) {
+      for (int i = 0; i < S6; ++i)
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_BIAS] + 3 * i + c] = (r == c) ? sw * b.bias_scale * bw[0][i] : 0.0;
+    } else {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_BIAS] + c] = (r == c) ? sw * b.bias_scale : 0.0;
+    }
+  }
+  // pose coefficients: block i = [ wdd_i * P | w_i Q0 + wd_i Q1 + wdd_i Q2 ]
+  double P[9], Q0[9], Q1[9], Q2[9];
+  if (!b.is_accel) {
+    m3_mul(Cib, G0w, Q0);
+    m3_mul(Cib, G1, Q1);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { P[i] = 0.0; Q2[i] = 0.0; }
+  } else {
+    // K = C_i_b is the chain into `inner`
+    double CbwS[9], Kv1[9], KC[9], T1[9], T2[9], Kr[9], KrG[9], Mw[9], So[9], Sor[9], Sr[9], tmp[9];
+    m3_mult(Cib, ps.C, P);              // C_i_b C_b_w : a_w chain  (acceleration node block = [wdd_i I | 0])
+    m3_tmul(ps.C, ps.S, CbwS);
+    // rotation node through RotationInverse: -K (v1)^ C_b_w S w_i
+    m3_skew(v1, Kv1);
+    m3_mul(Cib, Kv1, KC);
+    m3_mul(KC, CbwS, T1);               // K v1^ C_b_w S
+    // Cross(wdot_b, r_b) lhs: -K r^  ->  alpha node (w_i G0a + wdd_i G1)
+    m3_skew(rb, Sr);
+    m3_mul(Cib, Sr, Kr);                // K r^
+    m3_mul(Kr, G0a, KrG);
+    // Cross(w_b, Cross(w_b, r_b)): lhs -K (w x r)^ ; rhs K w^ then inner lhs -(K w^) r^
+    m3_skew(omxr, Sor);
+    m3_skew(om, So);
+    m3_mul(So, Sr, tmp);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tmp[i] = -(Sor[i] + tmp[i]);
+    m3_mul(Cib, tmp, Mw);               // Mw = -K((w x r)^ + w^ r^)
+    m3_mul(Mw, G0w, T2);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Q0[i] = -T1[i] - KrG[i] + T2[i];
+    m3_mul(Mw, G1, Q1);
+    m3_mul(Kr, G1, Q2);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Q2[i] = -Q2[i];
+    // gravity: -K C_b_w * Jg
+    if (rolecol[IMU_ROLE_G] >= 0) {
+      if (b.g_is_direction) {  // Jg = m [ -C[:,0]  C[:,1] ]  (ABE/src/EuclideanDirection.cpp:70-77)
+        const double* Cg = x + b.g.off;
+        double mg = Cg[9];
+        double c0[3] = {-mg * Cg[0], -mg * Cg[3], -mg * Cg[6]}, c1[3] = {mg * Cg[1], mg * Cg[4], mg * Cg[7]};
+        double o0[3], o1[3];
+        m3_mulv(P, c0, o0);
+        m3_mulv(P, c1, o1);
+        for (int r = 0; r < 3; ++r) {
+          J[r * ld + rolecol[IMU_ROLE_G]] = -sw * b.g.scale * o0[r];
+          J[r * ld + rolecol[IMU_ROLE_G] + 1] = -sw * b.g.scale * o1[r];
+        }
+      } else {
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_G] + c] = -sw * b.g.scale * P[3 * r + c];
+      }
+    }
+    // r_b: K (alpha^ + w^ w^)
+    if (rolecol[IMU_ROLE_RB] >= 0) {
+      double Sa[9], SS[9], R[9];
+      m3_skew(al, Sa);
+      m3_mul(So, So, SS);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) SS[i] += Sa[i];
+      m3_mul(Cib, SS, R);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_RB] + c] = sw * b.r_b.scale * R[3 * r + c];
+    }
+  }
+  if (rolecol[IMU_ROLE_POSE] >= 0) {
+    double f = sw * b.pose_scale;
+    for (int i = 0; i < S6; ++i) {
+      double w0 = ps.w[0][i], w1 = ps.w[1][i], w2 = b.is_accel ? ps.w[2][i] : 0.0;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          J[r * ld + rolecol[IMU_ROLE_POSE] + 6 * i + c] = f * w2 * P[3 * r + c];
+          J[r * ld + rolecol[IMU_ROLE_POSE] + 6 * i + 3 + c] = f * (w0 * Q0[3 * r + c] + w1 * Q1[3 * r + c] + w2 * Q2[3 * r + c]);
+        }
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F2: ReprojectionError with camera design variables over a static chain
+//   p_c = B_{n-1} * ... * B_0 * inverse(T_t_c) * p      (CameraCalibrator.py:195-212)
+// roles: 0 q_t_c, 1 t_t_c, 2+2j / 3+2j = q / t of baseline j (j < 4), 10 projection, 11 distortion
+enum { F2_ROLE_QTC = 0, F2_ROLE_TTC = 1, F2_ROLE_CHAIN = 2, F2_ROLE_PROJ = 10, F2_ROLE_DIST = 11, F2_MAX_CHAIN = 4 };
+struct StaticReprojBatchView {
+  CameraView cam;
+  int n_chain;
+  DvRef chain_q[F2_MAX_CHAIN], chain_t[F2_MAX_CHAIN];
+  double qtc_scale, ttc_scale, proj_scale, dist_scale;
+  const int* obs_first;
+  const int* obs_qtc_off;
+  const int* obs_ttc_off;
+  const int* term_obs;   // observation of each term
+  const double* y;
+  const double* p;
+  const double* sinv;
+  int mest; double mest_a;
+  int n_obs, n_terms, row_base, term_base_global;
+};
+MC_HD bool f2_term(const StaticReprojBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
+                   double* J, int ld, double* e, TermOut& out) {
+  int obs = b.term_obs[k];
+  Rigid Ttc, T;
+  load_rigid(x, b.obs_qtc_off[obs], b.obs_ttc_off[obs], Ttc);
+  rigid_inv(Ttc, T);  // T_c0_t
+  Rigid Tinv = T;     // inverse(T_t_c), kept for the leaf chain
+  Rigid pre[F2_MAX_CHAIN];  // pre[j] = transform to the right of baseline j (before multiplying B_j)
+  Rigid Bj[F2_MAX_CHAIN];
+  for (int j = 0; j < b.n_chain; ++j) {
+    pre[j] = T;
+    load_rigid(x, b.chain_q[j].off, b.chain_t[j].off, Bj[j]);
+    Rigid N;
+    rigid_mul(Bj[j], T, N);
+    T = N;
+  }
+  const double* pt = b.p + 3 * (size_t)k;
+  double pc[3];
+  m3_mulv(T.C, pt, pc);
+  pc[0] += T.r[0]; pc[1] += T.r[1]; pc[2] += T.r[2];
+  const double* pp = x + b.cam.proj_off;
+  const double* dk = b.cam.dist_off >= 0 ? x + b.cam.dist_off : x;
+  double kp[2], Jc[6];
+  project(b.cam.model, b.cam.dist, pp, dk, pc, kp, wantJ ? Jc : nullptr);
+  double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
+  double s = b.sinv[k];
+  out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
+  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
+  double sw = sqrt(out.w) * s;
+  e[0] = sw * e0; e[1] = sw * e1;
+  if (!wantJ) return true;
+  double Ji[12], Jd[8];
+  if (rolecol[F2_ROLE_PROJ] >= 0) intrinsics_jacobian(b.cam.model, b.cam.dist, pp, dk, pc, Ji);
+  if (rolecol[F2_ROLE_DIST] >= 0) distortion_jacobian(b.cam.model, b.cam.dist, pp, pc, Jd);
+  for (int r = 0; r < 2; ++r) {
+    double* row = J + r * ld;
+    double a[3] = {-sw * Jc[3 * r], -sw * Jc[3 * r + 1], -sw * Jc[3 * r + 2]};
+    double u[3] = {a[0], a[1], a[2]}, v[3];
+    v3_cross(a, pc, v);
+    // top-down through Multiply(B_j, rest): lhs gets the chain, rhs gets chain * boxTimes(B_j)
+    for (int j = b.n_chain - 1; j >= 0; --j) {
+      double Jq[3], Jt[3];
+      chain_basic(u, v, Bj[j].r, Jq, Jt);
+      int cq = rolecol[F2_ROLE_CHAIN + 2 * j], ct = rolecol[F2_ROLE_CHAIN + 2 * j + 1];
+      if (cq >= 0) for (int c = 0; c < 3; ++c) row[cq + c] = Jq[c] * b.chain_q[j].scale;
+      if (ct >= 0) for (int c = 0; c < 3; ++c) row[ct + c] = Jt[c] * b.chain_t[j].scale;
+      double u2[3], v2[3];
+      chain_boxtimes(u, v, Bj[j], u2, v2);
+      u[0] = u2[0]; u[1] = u2[1]; u[2] = u2[2]; v[0] = v2[0]; v[1] = v2[1]; v[2] = v2[2];
+    }
+    // inverse node: chain * (-boxTimes(inverse(T_t_c)))
+    double u2[3], v2[3], Jq[3], Jt[3];
+    chain_boxtimes(u, v, Tinv, u2, v2);
+    u2[0] = -u2[0]; u2[1] = -u2[1]; u2[2] = -u2[2]; v2[0] = -v2[0]; v2[1] = -v2[1]; v2[2] = -v2[2];
+    chain_basic(u2, v2, Ttc.r, Jq, Jt);
+    if (rolecol[F2_ROLE_QTC] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[F2_ROLE_QTC] + c] = Jq[c] * b.qtc_scale;
+    if (rolecol[F2_ROLE_TTC] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[F2_ROLE_TTC] + c] = Jt[c] * b.ttc_scale;
+    // camera design variables: -Jp, -Jd   (CameraDesignVariable.hpp:45-52)
+    if (rolecol[F2_ROLE_PROJ] >= 0)
+      for (int c = 0; c < b.cam.proj_dim; ++c) row[rolecol[F2_ROLE_PROJ] + c] = -sw * b.proj_scale * Ji[r * b.cam.proj_dim + c];
+    if (rolecol[F2_ROLE_DIST] >= 0)
+      for (int c = 0; c < 4; ++c) row[rolecol[F2_ROLE_DIST] + c] = -sw * b.dist_scale * Jd[r * 4 + c];
+  }
+  (void)pre;
+  return true;
+}
+
+}  // namespace mc

@@ -1,0 +1,194 @@
+// TEST INFRASTRUCTURE ONLY.  Compiles the product's term closed forms (multical_amd/csrc/mc_terms.h) and
+// structure analysis (mc_core.hpp) with g++ and evaluates single terms on the CPU, so that the `-m "not gpu"`
+// suite can compare the exact source the kernels are built from against the DAG-walking oracle before any GPU
+// time is spent.  It is not part of the package, is never imported by it, and has no role at run time: the
+// product path is the HIP library only.
+#include <memory>
+#include "../../multical_amd/csrc/mc_describe.hpp"
+
+using namespace mc;
+
+struct Probe {
+  Problem P;
+  std::string err;
+  // host copies of per-batch offset arrays (the device path uploads the same)
+  std::vector<std::vector<int>> obs_q_off, obs_t_off, term_q_off, term_t_off;
+  std::vector<int> term_batch, term_local;
+};
+
+#define PR_TRY try {
+#define PR_CATCH(p, rv) } catch (const std::exception& ex) { (p)->err = ex.what(); return rv; }
+
+static std::vector<int> offs(const Problem& P, const std::vector<int>& ids) {
+  std::vector<int> o(ids.size());
+  for (size_t i = 0; i < ids.size(); ++i) o[i] = P.dvs[ids[i]].off;
+  return o;
+}
+
+extern "C" {
+void* probe_create() { return new Probe(); }
+void probe_destroy(void* h) { delete (Probe*)h; }
+const char* probe_last_error(void* h) { return ((Probe*)h)->err.c_str(); }
+int probe_add_design_variable(void* h, int kind, const double* p, int n, int active, double scaling) {
+  Probe* pr = (Probe*)h; PR_TRY return pr->P.addDv(kind, p, n, active, scaling); PR_CATCH(pr, -1)
+}
+int probe_add_spline(void* h, int order, int dim, const double* k, int nk, const double* c, int nc, int active) {
+  Probe* pr = (Probe*)h; PR_TRY return pr->P.addSpline(order, dim, k, nk, c, nc, active); PR_CATCH(pr, -1)
+}
+int probe_add_camera(void* h, int model, int dist, int dp, int dd) {
+  Probe* pr = (Probe*)h; PR_TRY return pr->P.addCamera(model, dist, dp, dd); PR_CATCH(pr, -1)
+}
+int probe_add_reprojection_batch(void* h, int cam, int spline, int dq, int dt, int dtoff, int n_obs, const double* ot, const int* oq,
+                                 const int* otv, const int* of, const double* y, const double* p, const double* s, double pad, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeReprojection(pr->P, cam, spline, dq, dt, dtoff, n_obs, ot, oq, otv, of, y, p, s, pad, m, ma); return 0; PR_CATCH(pr, -1)
+}
+int probe_add_static_reprojection_batch(void* h, int cam, int nc, const int* cq, const int* ct, int n_obs, const int* oq, const int* ot,
+                                        const int* of, const double* y, const double* p, const double* s, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeStaticReprojection(pr->P, cam, nc, cq, ct, n_obs, oq, ot, of, y, p, s, m, ma); return 0; PR_CATCH(pr, -1)
+}
+int probe_add_accelerometer_batch(void* h, int ps, int bs, int db, int dg, int dq, int dr, int n, const double* t, const double* me,
+                                  const double* s, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeImu(pr->P, true, ps, bs, db, dg, dq, dr, n, t, me, s, m, ma); return 0; PR_CATCH(pr, -1)
+}
+int probe_add_gyroscope_batch(void* h, int ps, int bs, int db, int dq, int n, const double* t, const double* me, const double* s, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeImu(pr->P, false, ps, bs, db, -1, dq, -1, n, t, me, s, m, ma); return 0; PR_CATCH(pr, -1)
+}
+int probe_add_lidar_batch(void* h, int sp, int dtoff, int dq, int dt, int n, const double* t, const double* dir, const double* rg,
+                          const double* s, const int* q, const int* tv, double pad, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeLidar(pr->P, sp, dtoff, dq, dt, n, t, dir, rg, s, q, tv, pad, m, ma); return 0; PR_CATCH(pr, -1)
+}
+int probe_add_motion_term(void* h, int sp, const double* W, int order) {
+  Probe* pr = (Probe*)h; PR_TRY describeMotion(pr->P, sp, W, order); return 0; PR_CATCH(pr, -1)
+}
+int probe_set_shard(void* h, int rank, int world) { Probe* pr = (Probe*)h; pr->P.rank = rank; pr->P.world = world; return 0; }
+int probe_finalize(void* h) {
+  Probe* pr = (Probe*)h;
+  PR_TRY
+  Problem& P = pr->P;
+  P.finalize();
+  for (size_t b = 0; b < P.batches.size(); ++b) {
+    const Batch& B = P.batches[b];
+    pr->obs_q_off.push_back(offs(P, B.obs_dv_q)); pr->obs_t_off.push_back(offs(P, B.obs_dv_t));
+    pr->term_q_off.push_back(offs(P, B.term_dv_q)); pr->term_t_off.push_back(offs(P, B.term_dv_t));
+    for (int k = 0; k < B.n_terms; ++k) { pr->term_batch.push_back((int)b); pr->term_local.push_back(k); }
+  }
+  return 0;
+  PR_CATCH(pr, -1)
+}
+int probe_dims(void* h, int* jr, int* jc, int* nb, int* nt, int* nnz) {
+  Problem& P = ((Probe*)h)->P;
+  *jr = P.j_rows; *jc = P.j_cols; *nb = P.n_blocks; *nt = P.n_terms; *nnz = P.nnz;
+  return 0;
+}
+int probe_get_pattern(void* h, int* Cp, int* Ci) {
+  Problem& P = ((Probe*)h)->P;
+  std::memcpy(Cp, P.Cp.data(), sizeof(int) * P.Cp.size());
+  std::memcpy(Ci, P.Ci.data(), sizeof(int) * P.Ci.size());
+  return 0;
+}
+// number of groups kept by this rank / total (sharding checks)
+int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {
+  Problem& P = ((Probe*)h)->P;
+  *mine = *total = *my_terms = 0;
+  for (const Batch& b : P.batches) {
+    *mine += (int)b.my_groups.size(); *total += (int)b.groups.size();
+    for (const GroupRec& g : b.my_groups) *my_terms += g.term_count;
+  }
+  return 0;
+}
+// per-term flag: 1 if the term belongs to this rank's groups
+int probe_my_terms(void* h, int* flags) {
+  Problem& P = ((Probe*)h)->P;
+  int base = 0;
+  for (const Batch& b : P.batches) {
+    for (int k = 0; k < b.n_terms; ++k) flags[base + k] = (b.kind == KIND_MOTION && P.rank == 0) ? 1 : 0;
+    for (const GroupRec& g : b.my_groups) for (int k = 0; k < g.term_count; ++k) flags[base + g.term_first + k] = 1;
+    base += b.n_terms;
+  }
+  return 0;
+}
+
+// Dense weighted Jacobian rows (dim x j_cols, row-major), weighted residual and raw chi2 of one term, evaluated
+// with the product's closed forms at the current state P.x.  Returns the term dimension.
+int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2) {
+  Probe* pr = (Probe*)h;
+  PR_TRY
+  Problem& P = pr->P;
+  int bi = pr->term_batch[term], k = pr->term_local[term];
+  const Batch& B = P.batches[bi];
+  const double* x = P.x.data();
+  int JC = P.j_cols;
+  std::memset(Jd, 0, sizeof(double) * B.dim * JC);
+  TermOut out{0, 0};
+  int rolecol[MC_MAX_ROLES];
+  for (int r = 0; r < MC_MAX_ROLES; ++r) rolecol[r] = -1;
+  auto col = [&](int dv) { return dv >= 0 ? P.dvs[dv].col : -1; };
+  if (B.kind == KIND_REPROJ) {
+    ReprojBatchView v;
+    v.cam = P.cameraView(B.cam); v.sp = P.splineView(B.spline, P.knots.data(), P.basis.data());
+    v.q_cb = P.dvRef(B.dv[0]); v.t_cb = P.dvRef(B.dv[1]); v.toff = P.dvRef(B.dv[2]);
+    v.coef_scale = v.qpw_scale = v.tpw_scale = 1.0;
+    v.obs_time = B.t.data(); v.obs_first = B.obs_first.data(); v.obs_qpw_off = pr->obs_q_off[bi].data(); v.obs_tpw_off = pr->obs_t_off[bi].data();
+    v.y = B.y.data(); v.p = B.p.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    int obs = (int)(std::upper_bound(B.obs_first.begin(), B.obs_first.end(), k) - B.obs_first.begin()) - 1;
+    F1Common cm;
+    f1_common(v, x, obs, cm);
+    if (!cm.ok) throw std::runtime_error("time out of spline");
+    double core[2 * F1_CORE], ee[2];
+    f1_term(v, x, cm, k, useM != 0, true, core, ee, out);
+    rolecol[F1_ROLE_COEF] = v.sp.first_col >= 0 ? v.sp.first_col + 6 * cm.ps.seg : -1;
+    rolecol[F1_ROLE_QCB] = v.q_cb.col; rolecol[F1_ROLE_TCB] = v.t_cb.col;
+    rolecol[F1_ROLE_QPW] = col(B.obs_dv_q[obs]); rolecol[F1_ROLE_TPW] = col(B.obs_dv_t[obs]); rolecol[F1_ROLE_TOFF] = v.toff.col;
+    for (int r = 0; r < 2; ++r) { f1_expand_row(core + r * F1_CORE, cm.ps.w[0], rolecol, Jd + (size_t)r * JC); e[r] = ee[r]; }
+  } else if (B.kind == KIND_LIDAR) {
+    LidarBatchView v;
+    v.sp = P.splineView(B.spline, P.knots.data(), P.basis.data());
+    v.q_lb = P.dvRef(B.dv[0]); v.t_lb = P.dvRef(B.dv[1]); v.toff = P.dvRef(B.dv[2]);
+    v.coef_scale = v.qpw_scale = v.tpw_scale = 1.0;
+    v.t = B.t.data(); v.dir = B.p.data(); v.range = B.range.data(); v.sinv = B.sinv.data();
+    v.qpw_off = pr->term_q_off[bi].data(); v.tpw_off = pr->term_t_off[bi].data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    double t = B.t[k] + (v.toff.off >= 0 ? x[v.toff.off] : 0.0);
+    int seg = spline_segment(v.sp, t);
+    rolecol[F5_ROLE_COEF] = v.sp.first_col >= 0 ? v.sp.first_col + 6 * seg : -1;
+    rolecol[F5_ROLE_QLB] = v.q_lb.col; rolecol[F5_ROLE_TLB] = v.t_lb.col;
+    rolecol[F5_ROLE_QPW] = col(B.term_dv_q[k]); rolecol[F5_ROLE_TPW] = col(B.term_dv_t[k]); rolecol[F5_ROLE_TOFF] = v.toff.col;
+    if (!f5_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out)) throw std::runtime_error("time out of spline");
+  } else if (B.kind == KIND_ACCEL || B.kind == KIND_GYRO) {
+    ImuBatchView v;
+    v.pose = P.splineView(B.spline, P.knots.data(), P.basis.data());
+    v.bias = P.splineView(B.bias_spline, P.knots.data(), P.basis.data());
+    v.bias_dv = P.dvRef(B.dv[0]); v.g = P.dvRef(B.dv[1]); v.q_ib = P.dvRef(B.dv[2]); v.r_b = P.dvRef(B.dv[3]);
+    v.g_is_direction = (B.dv[1] >= 0 && P.dvs[B.dv[1]].kind == DV_EUCLIDEAN_DIRECTION) ? 1 : 0;
+    v.pose_scale = 1.0; v.bias_scale = B.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
+    v.t = B.t.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    v.is_accel = B.kind == KIND_ACCEL;
+    int seg = spline_segment(v.pose, B.t[k]);
+    rolecol[IMU_ROLE_POSE] = v.pose.first_col >= 0 ? v.pose.first_col + 6 * seg : -1;
+    if (B.bias_spline >= 0) { int bs = spline_segment(v.bias, B.t[k]); rolecol[IMU_ROLE_BIAS] = v.bias.first_col >= 0 ? v.bias.first_col + 3 * bs : -1; }
+    else rolecol[IMU_ROLE_BIAS] = v.bias_dv.col;
+    rolecol[IMU_ROLE_G] = v.g.col; rolecol[IMU_ROLE_QIB] = v.q_ib.col; rolecol[IMU_ROLE_RB] = v.r_b.col;
+    if (!imu_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out)) throw std::runtime_error("time out of spline");
+  } else if (B.kind == KIND_STATIC_REPROJ) {
+    StaticReprojBatchView v;
+    v.cam = P.cameraView(B.cam);
+    v.n_chain = (int)B.chain_q.size();
+    for (int j = 0; j < v.n_chain; ++j) { v.chain_q[j] = P.dvRef(B.chain_q[j]); v.chain_t[j] = P.dvRef(B.chain_t[j]); }
+    v.qtc_scale = v.ttc_scale = 1.0;
+    v.proj_scale = P.dvs[P.cams[B.cam].dv_proj].scaling;
+    v.dist_scale = P.cams[B.cam].dv_dist >= 0 ? P.dvs[P.cams[B.cam].dv_dist].scaling : 1.0;
+    v.obs_first = B.obs_first.data(); v.obs_qtc_off = pr->obs_q_off[bi].data(); v.obs_ttc_off = pr->obs_t_off[bi].data();
+    v.term_obs = B.term_obs.data(); v.y = B.y.data(); v.p = B.p.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    int obs = B.term_obs[k];
+    rolecol[F2_ROLE_QTC] = col(B.obs_dv_q[obs]); rolecol[F2_ROLE_TTC] = col(B.obs_dv_t[obs]);
+    for (int j = 0; j < v.n_chain; ++j) { rolecol[F2_ROLE_CHAIN + 2 * j] = v.chain_q[j].col; rolecol[F2_ROLE_CHAIN + 2 * j + 1] = v.chain_t[j].col; }
+    rolecol[F2_ROLE_PROJ] = v.cam.proj_col; rolecol[F2_ROLE_DIST] = v.cam.dist_col;
+    f2_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out);
+  } else {
+    throw std::runtime_error("probe_term: motion terms have no Jacobian");
+  }
+  *chi2 = out.chi2;
+  return B.dim;
+  PR_CATCH(pr, -1)
+}
+int probe_term_kind(void* h, int term) { Probe* pr = (Probe*)h; return pr->P.batches[pr->term_batch[term]].kind; }
+}
