@@ -30,7 +30,8 @@ struct DvRef {
 
 struct TermOut {
   double chi2;   // raw squared error  e^T invR e
-  double w;      // M-estimator weight w(chi2)
+  double w;      // M-estimator weight w(chi2): always applied to the cost (ErrorTerm::evaluateError, ErrorTerm.cpp:20-24);
+                 // the useMEstimator flag only gates the sqrt(w) on the residual / Jacobian rows
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -145,8 +146,8 @@ MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
   double s = b.sinv[k];
   out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
-  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
-  double sw = sqrt(out.w) * s;
+  out.w = mest_weight(b.mest, b.mest_a, out.chi2);
+  double sw = (useM ? sqrt(out.w) : 1.0) * s;
   e[0] = sw * e0; e[1] = sw * e1;
   if (!wantJ) return;
 #pragma unroll
@@ -231,8 +232,8 @@ MC_HD bool f5_term(const LidarBatchView& b, const double* x, int k, bool useM, b
   double e0 = pred - b.range[k];
   double s = b.sinv[k];
   out.chi2 = (s * e0) * (s * e0);
-  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
-  double sw = sqrt(out.w) * s;
+  out.w = mest_weight(b.mest, b.mest_a, out.chi2);
+  double sw = (useM ? sqrt(out.w) : 1.0) * s;
   e[0] = sw * e0;
   if (!wantJ) return true;
   // scalar chain: Multiply(., -1) -> -1 ; Divide(d, theta): a_d = -1/theta, a_th = d/theta^2
@@ -372,8 +373,8 @@ MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bo
   for (int d = 0; d < 3; ++d) ev[d] = pr[d] + bias[d] - m[d];
   double s = b.sinv[k];
   out.chi2 = (s * s) * (ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
-  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
-  double sw = sqrt(out.w) * s;
+  out.w = mest_weight(b.mest, b.mest_a, out.chi2);
+  double sw = (useM ? sqrt(out.w) : 1.0) * s;
   e[0] = sw * ev[0]; e[1] = sw * ev[1]; e[2] = sw * ev[2];
   if (!wantJ) return true;
 
@@ -520,8 +521,8 @@ MC_HD bool f2_term(const StaticReprojBatchView& b, const double* x, int k, bool 
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
   double s = b.sinv[k];
   out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
-  out.w = useM ? mest_weight(b.mest, b.mest_a, out.chi2) : 1.0;
-  double sw = sqrt(out.w) * s;
+  out.w = mest_weight(b.mest, b.mest_a, out.chi2);
+  double sw = (useM ? sqrt(out.w) : 1.0) * s;
   e[0] = sw * e0; e[1] = sw * e1;
   if (!wantJ) return true;
   double Ji[12], Jd[8];

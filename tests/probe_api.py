@@ -1,0 +1,122 @@
+"""ctypes adapter over tests/hostprobe/libhostprobe.so: the product's term closed forms (multical_amd/csrc/mc_terms.h) and
+structure analysis (mc_core.hpp) compiled with g++ for CPU-side checks.  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from oracle_api import _d, _i, _f64, _i32, ROOT
+
+PROBE_DIR = os.path.join(ROOT, "tests", "hostprobe")
+PROBE_LIB = os.path.join(PROBE_DIR, "libhostprobe.so")
+_L = None
+
+
+def _load():
+    global _L
+    if _L is None:
+        if not os.path.exists(PROBE_LIB):
+            subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                                   "-o", PROBE_LIB, os.path.join(PROBE_DIR, "hostprobe.cpp")])
+        _L = C.CDLL(PROBE_LIB)
+        _L.probe_create.restype = C.c_void_p
+        _L.probe_last_error.restype = C.c_char_p
+        _L.probe_last_error.argtypes = [C.c_void_p]
+    return _L
+
+
+class ProbeApi(object):
+    def __init__(self):
+        self.L = _load()
+        self.h = C.c_void_p(self.L.probe_create())
+        self.finalized = False
+
+    def __del__(self):
+        try:
+            self.L.probe_destroy(self.h)
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError("probe: " + self.L.probe_last_error(self.h).decode())
+        return rc
+
+    def add_design_variable(self, kind, params, active=True, scaling=1.0):
+        p = _f64(params)
+        return self._chk(self.L.probe_add_design_variable(self.h, C.c_int(kind), _d(p), C.c_int(p.size), C.c_int(int(bool(active))),
+                                                          C.c_double(scaling)))
+
+    def add_spline(self, order, dim, knots, coeffs, active=True):
+        k = _f64(knots)
+        c = np.ascontiguousarray(_f64(coeffs).T)
+        return self._chk(self.L.probe_add_spline(self.h, C.c_int(order), C.c_int(dim), _d(k), C.c_int(k.size), _d(c),
+                                                 C.c_int(c.shape[0]), C.c_int(int(bool(active)))))
+
+    def add_camera(self, m, d, a, b=-1):
+        return self._chk(self.L.probe_add_camera(self.h, C.c_int(m), C.c_int(d), C.c_int(a), C.c_int(b)))
+
+    def add_reprojection_batch(self, cam, spline, dq, dt, dtoff, ot, oq, otv, of, y, p, s, pad, m=0, ma=0.0):
+        ot, y, p, s = _f64(ot), _f64(y), _f64(p), _f64(s)
+        oq, otv, of = _i32(oq), _i32(otv), _i32(of)
+        self._chk(self.L.probe_add_reprojection_batch(self.h, C.c_int(cam), C.c_int(spline), C.c_int(dq), C.c_int(dt), C.c_int(dtoff),
+                                                      C.c_int(ot.size), _d(ot), _i(oq), _i(otv), _i(of), _d(y), _d(p), _d(s),
+                                                      C.c_double(pad), C.c_int(m), C.c_double(ma)))
+
+    def add_static_reprojection_batch(self, cam, cq, ct, oq, ot, of, y, p, s, m=0, ma=0.0):
+        y, p, s = _f64(y), _f64(p), _f64(s)
+        cq, ct, oq, ot, of = _i32(cq), _i32(ct), _i32(oq), _i32(ot), _i32(of)
+        self._chk(self.L.probe_add_static_reprojection_batch(self.h, C.c_int(cam), C.c_int(cq.size), _i(cq), _i(ct), C.c_int(oq.size),
+                                                             _i(oq), _i(ot), _i(of), _d(y), _d(p), _d(s), C.c_int(m), C.c_double(ma)))
+
+    def add_accelerometer_batch(self, ps, bs, db, dg, dq, dr, t, me, s, m=0, ma=0.0):
+        t, me, s = _f64(t), _f64(me), _f64(s)
+        self._chk(self.L.probe_add_accelerometer_batch(self.h, C.c_int(ps), C.c_int(bs), C.c_int(db), C.c_int(dg), C.c_int(dq),
+                                                       C.c_int(dr), C.c_int(t.size), _d(t), _d(me), _d(s), C.c_int(m), C.c_double(ma)))
+
+    def add_gyroscope_batch(self, ps, bs, db, dq, t, me, s, m=0, ma=0.0):
+        t, me, s = _f64(t), _f64(me), _f64(s)
+        self._chk(self.L.probe_add_gyroscope_batch(self.h, C.c_int(ps), C.c_int(bs), C.c_int(db), C.c_int(dq), C.c_int(t.size), _d(t),
+                                                   _d(me), _d(s), C.c_int(m), C.c_double(ma)))
+
+    def add_lidar_batch(self, sp, dtoff, dq, dt, t, dr, rg, s, q, tv, pad, m=0, ma=0.0):
+        t, dr, rg, s = _f64(t), _f64(dr), _f64(rg), _f64(s)
+        q, tv = _i32(q), _i32(tv)
+        self._chk(self.L.probe_add_lidar_batch(self.h, C.c_int(sp), C.c_int(dtoff), C.c_int(dq), C.c_int(dt), C.c_int(t.size), _d(t),
+                                               _d(dr), _d(rg), _d(s), _i(q), _i(tv), C.c_double(pad), C.c_int(m), C.c_double(ma)))
+
+    def add_motion_term(self, sp, W, order):
+        W = _f64(W)
+        self._chk(self.L.probe_add_motion_term(self.h, C.c_int(sp), _d(W), C.c_int(order)))
+
+    def set_shard(self, rank, world):
+        self.L.probe_set_shard(self.h, C.c_int(rank), C.c_int(world))
+
+    def finalize(self):
+        self._chk(self.L.probe_finalize(self.h))
+        v = [C.c_int() for _ in range(5)]
+        self.L.probe_dims(self.h, *[C.byref(x) for x in v])
+        self.j_rows, self.j_cols, self.n_blocks, self.n_terms, self.nnz = [x.value for x in v]
+        self.finalized = True
+
+    def pattern(self):
+        Cp = np.empty(self.j_cols + 1, np.int32)
+        Ci = np.empty(self.nnz, np.int32)
+        self.L.probe_get_pattern(self.h, _i(Cp), _i(Ci))
+        return Cp, Ci
+
+    def term(self, t, use_mest=True):
+        J = np.zeros((3, self.j_cols))
+        e = np.zeros(3)
+        c = C.c_double()
+        d = self._chk(self.L.probe_term(self.h, C.c_int(t), C.c_int(int(use_mest)), _d(J), _d(e), C.byref(c)))
+        return J[:d], e[:d], c.value
+
+    def term_kind(self, t):
+        return self.L.probe_term_kind(self.h, C.c_int(t))
+
+    def my_terms(self):
+        f = np.zeros(self.n_terms, np.int32)
+        self.L.probe_my_terms(self.h, _i(f))
+        return f.astype(bool)

@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Bar (north_star): sparsity pattern / block indexing bit-exact; residuals, Jacobians (through H), H and b within 1e-9
+relative in fp64; final calibration estimates within 1e-7."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _hip(spec, rank=None, world=None):
+    from multical_amd.backend import HipApi
+    g = HipApi(0)
+    if world:
+        g.set_shard(rank, world)
+    ids = spec.emit(g)
+    g.finalize()
+    return g, ids
+
+
+def _close(a, b, rtol=RTOL):
+    """|a-b| <= rtol * max|b| entrywise (values are sums of many terms, so the scale of the array is the yardstick) and
+    the 2-norm relative error likewise."""
+    scale = np.abs(b).max()
+    assert np.abs(a - b).max() <= rtol * scale, (np.abs(a - b).max(), scale)
+    assert np.linalg.norm(a - b) <= rtol * np.linalg.norm(b)
+
+
+@pytest.fixture(scope="module")
+def hip_small(small_problem):
+    return _hip(small_problem["spec"])
+
+
+def test_native_library_is_loaded(hip_small):
+    g, _ = hip_small
+    name, n_cu, gib = g.device_info()
+    assert "gfx950" in name, name
+    maps = open("/proc/self/maps").read()
+    assert "libmulticalhip.so" in maps
+
+
+def test_pattern_bit_exact(hip_small, small_oracle):
+    g, _ = hip_small
+    o, _ = small_oracle
+    o.evaluate_error(True)
+    Cp, Ci, Cx, rhs = o.build_system(True)
+    Cpg, Cig = g.pattern()
+    assert (g.j_rows, g.j_cols, g.n_blocks, g.n_terms) == (o.j_rows, o.j_cols, o.n_blocks, o.n_terms)
+    assert np.array_equal(Cp, Cpg) and np.array_equal(Ci, Cig)
+
+
+def test_block_indices_match(hip_small, small_oracle, small_problem):
+    g, ids = hip_small
+    o, oids = small_oracle
+    for h, v in ids.items():
+        if isinstance(v, int) and small_problem["spec"].ops[h][0] == "dv":
+            assert g.dv_block(v) == o.dv_block(oids[h])
+
+
+@pytest.mark.parametrize("use_mest", [True, False])
+def test_evaluate_error(hip_small, small_oracle, use_mest):
+    g, _ = hip_small
+    o, _ = small_oracle
+    Jo, eo = o.evaluate_error(use_mest)
+    Jg, eg = g.evaluate_error(use_mest)
+    assert abs(Jg - Jo) <= RTOL * abs(Jo)
+    _close(eg, eo)
+    co, cg = o.term_chi2(), g.term_chi2()
+    assert np.abs(co - cg).max() <= RTOL * np.abs(co).max()
+    assert np.all(np.abs(co - cg) <= 1e-7 * np.abs(co) + 1e-12)
+
+
+@pytest.mark.parametrize("use_mest", [True, False])
+def test_build_system(hip_small, small_oracle, use_mest):
+    g, _ = hip_small
+    o, _ = small_oracle
+    o.evaluate_error(use_mest)
+    Cp, Ci, Cx, rhs = o.build_system(use_mest)
+    Cxg, rhsg = g.build_system(use_mest)
+    _close(Cxg, Cx)
+    _close(rhsg, rhs)
+    # per block column: relative to the column's own scale (small blocks must be right too)
+    col_of = np.repeat(np.arange(o.j_cols), np.diff(Cp))
+    cmax = np.zeros(o.j_cols)
+    np.maximum.at(cmax, col_of, np.abs(Cx))
+    rmax = np.zeros(o.j_cols)
+    np.maximum.at(rmax, Ci, np.abs(Cx))
+    tol = RTOL * np.sqrt(np.maximum(cmax[col_of], 1e-300) * np.maximum(np.maximum(rmax, cmax)[Ci], 1e-300)) * 10
+    assert np.all(np.abs(Cxg - Cx) <= tol)
+    # structural zeros of padded coefficients stay exact zeros
+    assert np.array_equal(Cxg == 0.0, Cx == 0.0) or np.all(Cxg[Cx == 0.0] == 0.0)
+
+
+def test_build_is_repeatable(hip_small):
+    g, _ = hip_small
+    a, ra = g.build_system(True)
+    b, rb = g.build_system(True)
+    _close(a, b, 1e-12)
+    _close(ra, rb, 1e-12)
+
+
+def test_update_and_revert(hip_small, small_oracle, small_problem):
+    g, ids = hip_small
+    o, oids = small_oracle
+    rng = np.random.default_rng(5)
+    dx = 2e-3 * rng.standard_normal(g.j_cols)
+    J0, _ = g.evaluate_error(True)
+    g.apply_update(dx)
+    o.apply_update(dx)
+    try:
+        Jg, eg = g.evaluate_error(True)
+        Jo, eo = o.evaluate_error(True)
+        assert abs(Jg - Jo) <= RTOL * abs(Jo)
+        _close(eg, eo)
+        for h, v in ids.items():
+            if isinstance(v, int) and small_problem["spec"].ops[h][0] == "dv":
+                pg, po = g.dv_params(v), o.dv_params(oids[h])
+                assert np.abs(pg - po).max() <= 1e-12 * max(1.0, np.abs(po).max()), (h, pg, po)
+        Cp, Ci, Cx, rhs = o.build_system(True)
+        Cxg, rhsg = g.build_system(True)
+        _close(Cxg, Cx)
+        _close(rhsg, rhs)
+    finally:
+        g.revert_update()
+        o.revert_update()
+        o.evaluate_error(True)
+    J1, _ = g.evaluate_error(True)
+    assert J1 == J0
+
+
+def test_two_shards_sum_to_the_whole(small_problem, hip_small):
+    g, _ = hip_small
+    Cx, rhs = g.build_system(True)
+    J, e = g.evaluate_error(True)
+    parts = [_hip(small_problem["spec"], r, 2)[0] for r in range(2)]
+    Cxs = rhss = Js = es = 0
+    for p in parts:
+        a, b = p.build_system(True)
+        j, ee = p.evaluate_error(True)
+        Cxs, rhss, Js, es = Cxs + a, rhss + b, Js + j, es + ee
+    _close(Cxs, Cx, 1e-12)
+    _close(rhss, rhs, 1e-12)
+    assert abs(Js - J) <= 1e-12 * J
+    _close(es, e, 1e-15)
+
+
+def test_device_pointer_entry_points(hip_small):
+    import torch
+    g, _ = hip_small
+    Cx, rhs = g.build_system(True)
+    J, e = g.evaluate_error(True)
+    dCx = torch.full((g.nnz,), 7.0, dtype=torch.float64, device="cuda:0")
+    drhs = torch.full((g.j_cols,), 7.0, dtype=torch.float64, device="cuda:0")
+    dJ = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    de = torch.zeros(g.j_rows, dtype=torch.float64, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    g.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), st)
+    g.evaluate_error_device(True, dJ.data_ptr(), de.data_ptr(), st)
+    torch.cuda.synchronize()
+    _close(dCx.cpu().numpy(), Cx, 1e-12)
+    _close(drhs.cpu().numpy(), rhs, 1e-12)
+    assert abs(dJ.item() - J) <= 1e-12 * J
+    assert np.array_equal(de.cpu().numpy(), e)
+
+
+def test_time_offset_buffer_exceeded_is_reported(small_problem):
+    """TransformationTimeOffsetExpressionNode throws 'Spline Coefficient Buffer Exceeded' when the time offset leaves the
+    frozen buffer (BSplineExpressions.cpp:447, 503)."""
+    from multical_amd.backend import BackendError
+    g, ids = _hip(small_problem["spec"])
+    H = small_problem["H"]
+    b, c = g.dv_block(ids[H["cams"][0]["toff"]])
+    dx = np.zeros(g.j_cols)
+    dx[c] = 0.08     # > padding (0.03 s) + one 10 ms segment
+    g.apply_update(dx)
+    with pytest.raises(BackendError, match="Buffer Exceeded"):
+        g.evaluate_error(True)
+
+
+def test_levenberg_marquardt_matches_oracle(small_problem):
+    """Optimizer2 + LM policy on the HIP backend vs the oracle's restatement of the same loop: same iteration
+    counts, final estimates within 1e-7."""
+    from multical_amd import backend as B
+    from oracle_api import OracleApi
+    spec = small_problem["spec"]
+    g, ids = _hip(spec)
+    o = OracleApi()
+    oids = spec.emit(o)
+    o.finalize()
+    opt = B.Optimizer2Options()
+    opt.maxIterations, opt.convergenceDeltaX, opt.convergenceJDescentRatioThreshold = 8, 1e-5, 1e-6
+    opt.linearSolver = B.HipBlockCholeskyLinearSystemSolver(g)
+    opt.trustRegionPolicy = B.LevenbergMarquardtTrustRegionPolicy(10.0)
+    srv = B.Optimizer2(opt).optimize()
+    ro = o.optimize(8, 10.0, 1e-5, 1e-6, 4)
+    assert srv.iterations == ro["iterations"] and srv.failedIterations == ro["failedIterations"]
+    assert abs(srv.JFinal - ro["JFinal"]) <= 1e-7 * ro["JFinal"]
+    assert srv.JFinal < 0.5 * srv.JStart
+    worst = 0.0
+    for h, v in ids.items():
+        if isinstance(v, int) and spec.ops[h][0] == "dv":
+            worst = max(worst, np.abs(g.dv_params(v) - o.dv_params(oids[h])).max())
+    assert worst <= 1e-7, worst
+    first = g.lib.mc_spline_first_dv(g.ctx, ids[small_problem["H"]["pose"]][1])
+    ofirst = o.spline_first_dv(oids[small_problem["H"]["pose"]][1])
+    for i in range(0, 200, 7):
+        worst = max(worst, np.abs(g.dv_params(first + i) - o.dv_params(ofirst + i)).max())
+    assert worst <= 1e-7, worst
+
+
+def test_medium_problem_properties():
+    """Properties that do not need the oracle, at a size it would take minutes for: H is symmetric PSD on random
+    vectors, scaling every sqrtInvR by 2 scales H and b by 4, and two builds agree."""
+    from multical_amd import synth
+    from multical_amd.backend import HipApi
+    cfg = synth.SynthConfig(duration=20.0, n_cams=2, n_imus=2, n_lidars=1, lidar_points_per_frame=100)
+    W = synth.make_world(cfg)
+    meas = synth.synthesize(W, lambda: HipApi(0))
+    spec, H = synth.build_spec(W, synth.initial_state(W), meas, with_mest=False)
+    g, _ = _hip(spec)
+    Cx, rhs = g.build_system(False)
+    Cp, Ci = g.pattern()
+    import scipy.sparse as sp
+    n = g.j_cols
+    U = sp.csc_matrix((Cx, Ci, Cp), shape=(n, n))
+    A = U + sp.triu(U, 1).T
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        v = rng.standard_normal(n)
+        assert v @ (A @ v) >= -1e-9 * np.abs(Cx).max()
+    cfg2 = synth.SynthConfig(duration=20.0, n_cams=2, n_imus=2, n_lidars=1, lidar_points_per_frame=100,
+                             reproj_sigma=0.5, accel_sigma=0.14, gyro_sigma=0.012, lidar_sigma=0.01, bias_motion_terms=False)
+    cfg.bias_motion_terms = False
+    W["cfg"] = cfg
+    spec1, _ = synth.build_spec(W, synth.initial_state(W), meas, with_mest=False)
+    W["cfg"] = cfg2
+    spec2, _ = synth.build_spec(W, synth.initial_state(W), meas, with_mest=False)
+    g1, _ = _hip(spec1)
+    g2, _ = _hip(spec2)
+    a1, r1 = g1.build_system(False)
+    a2, r2 = g2.build_system(False)
+    _close(a2, 4.0 * a1, 1e-12)
+    _close(r2, 4.0 * r1, 1e-12)

@@ -1,0 +1,59 @@
+"""The product's closed-form term math (mc_terms.h, compiled with g++ by tests/hostprobe) against the DAG-walking oracle,
+term by term, plus bit-exact pattern / indexing.  Runs without a GPU."""
+import numpy as np
+import pytest
+
+from probe_api import ProbeApi
+
+
+@pytest.fixture(scope="module")
+def probe(small_problem):
+    p = ProbeApi()
+    small_problem["spec"].emit(p)
+    p.finalize()
+    return p
+
+
+def test_dimensions_and_block_indices(probe, small_oracle):
+    o, ids = small_oracle
+    assert (probe.j_rows, probe.j_cols, probe.n_blocks, probe.n_terms) == (o.j_rows, o.j_cols, o.n_blocks, o.n_terms)
+
+
+def test_pattern_is_bit_exact(probe, small_oracle):
+    o, _ = small_oracle
+    o.evaluate_error(True)
+    Cp, Ci, Cx, rhs = o.build_system(True)
+    Cp2, Ci2 = probe.pattern()
+    assert np.array_equal(Cp, Cp2)
+    assert np.array_equal(Ci, Ci2)
+
+
+@pytest.mark.parametrize("use_mest", [True, False])
+def test_every_term_matches_oracle(probe, small_oracle, use_mest):
+    o, _ = small_oracle
+    o.evaluate_error(use_mest)
+    chi = o.term_chi2()
+    worst_j = worst_e = worst_c = 0.0
+    for t in range(o.n_terms):
+        if probe.term_kind(t) == 5:
+            continue
+        Ja, ea = o.term_weighted_jacobian(t, use_mest)
+        Jp, ep, c = probe.term(t, use_mest)
+        worst_j = max(worst_j, np.abs(Ja - Jp).max() / np.abs(Ja).max())
+        worst_e = max(worst_e, np.abs(ea - ep).max() / max(1e-9, np.abs(ea).max()))
+        worst_c = max(worst_c, abs(c - chi[t]) / max(1e-9, chi[t]))
+    assert worst_j < 1e-9 and worst_e < 1e-9 and worst_c < 1e-9, (worst_j, worst_e, worst_c)
+
+
+def test_sharding_partitions_terms(small_problem):
+    flags = []
+    for r in range(3):
+        p = ProbeApi()
+        p.set_shard(r, 3)
+        small_problem["spec"].emit(p)
+        p.finalize()
+        flags.append(p.my_terms())
+    total = np.sum(flags, 0)
+    assert np.all(total == 1)
+    sizes = [int(f.sum()) for f in flags]
+    assert min(sizes) > 0.2 * max(sizes), sizes
