@@ -53,6 +53,23 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if this library pulled in
+    the system copy as well, whichever runtime initialises second finds no device ("No HIP GPUs are available").  When
+    torch is installed, its copy is loaded first with RTLD_GLOBAL so that libmulticalhip.so binds to the same one and
+    device pointers / streams can be shared with torch (bench.py, RCCL all-reduce)."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libmulticalhip.so (once) and declare every entry point.  Raises if it is not built."""
     global _lib
@@ -62,6 +79,7 @@ def load():
         raise RuntimeError(
             "multical_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -334,9 +334,10 @@ class LevenbergMarquardtTrustRegionPolicy(object):
         if self._isFirstIteration:
             self._solver.buildSystem(nThreads, True)
         else:
-            d1 = self._p_J - self._J
-            d2 = float(self._dx @ (self._lambda * self._dx + self._solver.rhs()))
-            rho = d1 / d2
+            d1 = np.float64(self._p_J - self._J)
+            d2 = np.float64(self._dx @ (self._lambda * self._dx + self._solver.rhs()))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rho = d1 / d2          # IEEE semantics like the C++ (inf / nan, no exception)
             if previousIterationFailed:
                 self._mu *= 2
                 self._lambda *= self._mu

@@ -45,6 +45,7 @@ class SynthConfig(object):
         self.accel_sigma = 0.28
         self.gyro_sigma = 0.024
         self.lidar_sigma = 0.02
+        self.motion_speed = 1.0           # time scale of the trajectory (tests use > 1 for well-excited lever arms)
         self.perturb = 1.0                # scale of the initial-guess perturbation
         self.t_start = 0.0                # window start (multi-GPU weak scaling shifts nothing: one long trajectory)
         for k, v in kw.items():
@@ -68,8 +69,8 @@ def baseline_config(index, **over):
     return SynthConfig(**c)
 
 
-def trajectory(t):
-    t = np.asarray(t, dtype=np.float64)
+def trajectory(t, speed=1.0):
+    t = np.asarray(t, dtype=np.float64) * speed
     r = np.stack([1.5 * np.sin(0.4 * t), 1.0 * np.sin(0.31 * t + 0.7), 0.3 * np.sin(0.53 * t)], 0)
     th = np.stack([0.3 * np.sin(0.37 * t), 0.25 * np.sin(0.29 * t + 1.1), 0.6 * np.sin(0.21 * t)], 0)
     return np.concatenate([r, th], 0)   # 6 x n
@@ -144,7 +145,7 @@ def make_world(cfg):
     knots = t0 + (np.arange(n_seg + 2 * SPLINE_ORDER - 1) - (SPLINE_ORDER - 1)) * dt
     n_coef = n_seg + SPLINE_ORDER - 1
     grev = np.array([knots[i + 1:i + SPLINE_ORDER].mean() for i in range(n_coef)])
-    W["pose_knots"], W["pose_coeffs"] = knots, trajectory(grev)
+    W["pose_knots"], W["pose_coeffs"] = knots, trajectory(grev, cfg.motion_speed)
     W["t_min"], W["t_max"] = knots[SPLINE_ORDER - 1], knots[-SPLINE_ORDER]
     # ---- boards around +x, facing the origin
     pts = aprilgrid_points()
@@ -181,7 +182,7 @@ def make_world(cfg):
     for c, cam in enumerate(cams):
         ft = cfg.t_start + (np.arange(n_frames) + 0.5 * (c % 2)) / cfg.cam_rate + 0.01
         ft = ft[(ft > W["t_min"] + pad) & (ft < W["t_max"] - pad)]
-        pose = trajectory(ft)
+        pose = trajectory(ft, cfg.motion_speed)
         C_w_b = rotvec_to_matrix(pose[3:].T)                    # n x 3 x 3
         obs_time, obs_board, obs_first, corner_idx = [], [], [0], []
         fu, fv, cu, cv = 460.0, 460.0, 376.0, 240.0
@@ -211,7 +212,10 @@ def make_world(cfg):
     bknots = tb0 + (np.arange(nb_seg + 2 * SPLINE_ORDER - 1) - (SPLINE_ORDER - 1)) * bdt
     nb_coef = nb_seg + SPLINE_ORDER - 1
     for i in range(cfg.n_imus):
-        t = cfg.t_start + (np.arange(int(cfg.duration * cfg.imu_rate)) + 0.37) / cfg.imu_rate + 1e-3 * i
+        # the IMU stream spans the whole spline (recordings start before / end after the camera data; terms are kept
+        # while t_min < t < t_max, sensors_and_targets.py:1154), so the padding coefficients are observed too
+        n_imu = int(np.ceil((tb1 - tb0) * cfg.imu_rate)) + 1
+        t = tb0 + (np.arange(n_imu) + 0.37) / cfg.imu_rate + 1e-4 * i
         t = t[(t > tb0) & (t < tb1)]
         C_i_b = _small_rotation(rng, 0.3) if i else np.eye(3)
         imus.append(dict(t=t, q=quat_from_matrix(C_i_b), r=rng.uniform(-0.2, 0.2, 3) if i else np.zeros(3), reference=(i == 0),
@@ -235,7 +239,7 @@ def make_world(cfg):
         Rwp = np.stack([b["C"].T for b in boards])[board]
         twp = np.stack([-b["C"].T @ b["t"] for b in boards])[board]
         pw = np.einsum("nij,nj->ni", Rwp, pb) + twp
-        pose = trajectory(tt)
+        pose = trajectory(tt, cfg.motion_speed)
         C_w_b = rotvec_to_matrix(pose[3:].T)
         pbody = np.einsum("nji,nj->ni", C_w_b, pw - pose[:3].T)
         pl = pbody @ C_l_b.T + t_l_b

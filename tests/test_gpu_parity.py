@@ -178,32 +178,39 @@ def test_time_offset_buffer_exceeded_is_reported(small_problem):
         g.evaluate_error(True)
 
 
-def test_levenberg_marquardt_matches_oracle(small_problem):
-    """Optimizer2 + LM policy on the HIP backend vs the oracle's restatement of the same loop: same iteration
-    counts, final estimates within 1e-7."""
-    from multical_amd import backend as B
+def test_levenberg_marquardt_matches_oracle():
+    """Optimizer2 + LM policy on the HIP backend vs the oracle's restatement of the same loop (including the
+    lambda^2 / lambda un-augment quirk and the no-rebuild-after-rejection rule): same accepted / rejected step sequence,
+    final estimates within 1e-7.  The host solve differs (SuperLU here, dense Cholesky in the oracle, CHOLMOD in the
+    reference), so the run is kept to the iterations where lambda still conditions the system."""
+    from multical_amd import backend as B, synth
+    from multical_amd.backend import HipApi
     from oracle_api import OracleApi
-    spec = small_problem["spec"]
+    cfg = synth.SynthConfig(duration=2.0, n_cams=3, n_imus=2, n_lidars=1, lidar_points_per_frame=20, corner_stride=9,
+                            cam_models=[(0, 1), (1, 1), (2, 0)], huber_accel=1.0, huber_gyro=1.0, blake_zisserman_cam=2,
+                            lidar_mest=(2, 4.0), motion_speed=5.0)
+    spec, H, W, meas = synth.make_problem(cfg, lambda: HipApi(0))
     g, ids = _hip(spec)
     o = OracleApi()
     oids = spec.emit(o)
     o.finalize()
+    iters = 6
     opt = B.Optimizer2Options()
-    opt.maxIterations, opt.convergenceDeltaX, opt.convergenceJDescentRatioThreshold = 8, 1e-5, 1e-6
+    opt.maxIterations, opt.convergenceDeltaX, opt.convergenceJDescentRatioThreshold = iters, 1e-5, 1e-6
     opt.linearSolver = B.HipBlockCholeskyLinearSystemSolver(g)
     opt.trustRegionPolicy = B.LevenbergMarquardtTrustRegionPolicy(10.0)
     srv = B.Optimizer2(opt).optimize()
-    ro = o.optimize(8, 10.0, 1e-5, 1e-6, 4)
+    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 4)
     assert srv.iterations == ro["iterations"] and srv.failedIterations == ro["failedIterations"]
     assert abs(srv.JFinal - ro["JFinal"]) <= 1e-7 * ro["JFinal"]
-    assert srv.JFinal < 0.5 * srv.JStart
+    assert srv.JFinal < 0.1 * srv.JStart
     worst = 0.0
     for h, v in ids.items():
         if isinstance(v, int) and spec.ops[h][0] == "dv":
             worst = max(worst, np.abs(g.dv_params(v) - o.dv_params(oids[h])).max())
     assert worst <= 1e-7, worst
-    first = g.lib.mc_spline_first_dv(g.ctx, ids[small_problem["H"]["pose"]][1])
-    ofirst = o.spline_first_dv(oids[small_problem["H"]["pose"]][1])
+    first = g.spline_first_dv(ids[H["pose"]][1])
+    ofirst = o.spline_first_dv(oids[H["pose"]][1])
     for i in range(0, 200, 7):
         worst = max(worst, np.abs(g.dv_params(first + i) - o.dv_params(ofirst + i)).max())
     assert worst <= 1e-7, worst
