@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py -- error-terms/s of one Gauss-Newton iteration's evaluateError + buildSystem on MI355X.
+
+A step = LinearSystemSolver::evaluateError followed by BlockCholeskyLinearSystemSolver::buildSystem over the whole
+synthetic problem (inputs resident in HBM), plus -- for N > 1 -- the RCCL all-reduce of the partial H / b / J.
+Workload: BASELINE.json configs[3], the full Multical problem (3 IMUs + 4 cameras + 2 LiDARs, 6 boards, time
+offsets, 120 s) that north_star quotes its target on; with N GPUs the sequence is N x 120 s long and each rank owns one
+time window ("weak" scaling).  The host sparse Cholesky is not part of the step (north_star: timed separately; see
+--solve).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix peak (AMD spec sheet; MI355X_MICROARCH.md lists no fp64 row)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, help="index into BASELINE.json configs (1, 3 or 4)")
+    ap.add_argument("--duration", type=float, default=None, help="override the sequence length per GPU [s]")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=5.0)
+    ap.add_argument("--solve", action="store_true", help="also time one host sparse Cholesky solve (reported separately)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from multical_amd import synth
+    from multical_amd.backend import HipApi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    base = synth.baseline_config(args.config)
+    per_gpu = args.duration if args.duration is not None else base.duration
+    cfg = synth.baseline_config(args.config, duration=per_gpu * world)
+    t0 = time.time()
+    W = synth.make_world(cfg)
+    meas = synth.synthesize(W, lambda: HipApi(local_rank), noise=True)   # forward model at the truth, on this GPU
+    spec, H = synth.build_spec(W, synth.initial_state(W), meas)
+    api = HipApi(local_rank)
+    if world > 1:
+        api.set_shard(rank, world)
+    spec.emit(api)
+    api.finalize()
+    t_setup = time.time() - t0
+
+    dev = torch.device("cuda", local_rank)
+    dCx = torch.zeros(api.nnz, dtype=torch.float64, device=dev)
+    drhs = torch.zeros(api.j_cols, dtype=torch.float64, device=dev)
+    dJ = torch.zeros(1, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        api.evaluate_error_device(True, dJ.data_ptr(), None, stream)
+        api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), stream)
+        if world > 1:
+            dist.all_reduce(dCx)
+            dist.all_reduce(drhs)
+            dist.all_reduce(dJ)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    api.check_status()
+    ms_per_step = dt / args.steps * 1e3
+    n_terms = api.n_terms
+    value = n_terms / (dt / args.steps)
+
+    # ---- per-kernel timing (HIP events on the launch stream, inside the C ABI) and roofline of the dominant kernel
+    info, counts = api.batch_info(), api.batch_counts()
+    reps = max(3, min(10, args.steps))
+    ms_build = np.zeros(len(info))
+    ms_eval = np.zeros(len(info))
+    for _ in range(reps):
+        ms_build += api.build_system_timed(True, True)
+        ms_eval += api.build_system_timed(True, False)
+    ms_build /= reps
+    ms_eval /= reps
+    kind_names = {0: "k_reproj", 1: "k_group<StaticReproj>", 2: "k_group<Imu>", 3: "k_group<Imu>", 4: "k_group<Lidar>", 5: "k_motion"}
+    per_kernel = {}
+    for (kind, nt, ng), (fd, fl, rb), mb, me in zip(info, counts, ms_build, ms_eval):
+        d = per_kernel.setdefault(kind_names[kind], dict(ms=0.0, launches=0, flops_dense=0.0, flops_live=0.0, rec_bytes=0.0, terms=0, eval_ms=0.0))
+        if ng == 0:
+            continue
+        # this rank's share of the batch
+        share = 1.0 / world if world > 1 else 1.0
+        d["ms"] += mb; d["eval_ms"] += me; d["launches"] += 1
+        d["flops_dense"] += fd * share; d["flops_live"] += fl * share; d["rec_bytes"] += rb * share; d["terms"] += nt * share
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
+    pk = per_kernel[dom]
+    avg_launch_ms = pk["ms"] / max(1, pk["launches"])
+    # algorithmic bytes of this kernel's launches: records + the Hessian / gradient entries it must produce + the state
+    state_bytes = 8.0 * sum(d["params"].size if k == "dv" else d["coeffs"].size for k, d in spec.ops if k in ("dv", "spline"))
+    alg_bytes = pk["rec_bytes"] + (8.0 * (api.nnz + api.j_cols) + state_bytes) * (pk["ms"] / max(1e-9, float(ms_build.sum())))
+    tf_dense = pk["flops_dense"] / (pk["ms"] * 1e-3) / 1e12
+    tf_live = pk["flops_live"] / (pk["ms"] * 1e-3) / 1e12
+    gbs = alg_bytes / (pk["ms"] * 1e-3) / 1e9
+    roofline = dict(bound="mfma", kernel=dom, achieved=round(tf_dense, 4), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(tf_dense / FP64_PEAK_TFLOPS, 5), traffic=None,
+                    note="fp64 vector/matrix peak; 'achieved' counts the reference's dense per-term J^T J flops (SURVEY 8d)",
+                    achieved_live_flops=round(tf_live, 4), frac_live=round(tf_live / FP64_PEAK_TFLOPS, 5),
+                    hbm_achieved_gbs=round(gbs, 2), hbm_frac=round(gbs / HBM_PEAK_GBS, 5),
+                    avg_launch_ms=round(avg_launch_ms, 4), launches_per_step=pk["launches"],
+                    kernels_ms={k: round(v["ms"], 4) for k, v in per_kernel.items()},
+                    eval_kernels_ms={k: round(v["eval_ms"], 4) for k, v in per_kernel.items()})
+
+    out = dict(metric="error-terms/sec (evaluateError + buildSystem per GN iteration)", value=value, unit="error-terms/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload="BASELINE configs[%d]: %d IMUs + %d cameras + %d LiDARs, %d boards, time offsets, %.0f s per GPU"
+                           % (args.config, cfg.n_imus, cfg.n_cams, cfg.n_lidars, cfg.n_boards, per_gpu),
+                           error_terms=n_terms, j_rows=api.j_rows, j_cols=api.j_cols, nnz_upper=api.nnz, n_blocks=api.n_blocks,
+                           build_ms=round(float(ms_build.sum()), 4), evaluate_ms=round(float(ms_eval.sum()), 4),
+                           setup_s=round(t_setup, 2), sharding="time windows, global pattern, all-reduce of Cx/rhs/J" if world > 1 else "none"),
+               roofline=roofline)
+
+    if args.solve and rank == 0:
+        from multical_amd.backend import HipBlockCholeskyLinearSystemSolver
+        s = HipBlockCholeskyLinearSystemSolver(api)
+        s.initMatrixStructure(True)
+        s.buildSystem()
+        s.setConstantConditioner(10.0)
+        ts = time.perf_counter()
+        ok, dx = s.solveSystem()
+        out["config"]["host_cholesky_s"] = round(time.perf_counter() - ts, 3)
+        out["config"]["host_cholesky_ok"] = bool(ok)
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, synth)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, synth):
+    """The CPU oracle (a restatement in the reference's cost shape: per-term expression-DAG walk with heap matrices,
+    std::map JacobianContainer / SparseBlockMatrix, SERIAL buildSystem, evaluateError on nproc-1 threads) timed on a
+    bounded sample: the first `cpu_sample_seconds` of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_api import OracleApi
+    from multical_amd.backend import HipApi
+    cfg = synth.baseline_config(args.config, duration=args.cpu_sample_seconds)
+    W = synth.make_world(cfg)
+    meas = synth.synthesize(W, lambda: HipApi(0), noise=True)
+    spec, _ = synth.build_spec(W, synth.initial_state(W), meas)
+    o = OracleApi()
+    spec.emit(o)
+    o.finalize()
+    cores = min(16, max(1, (os.cpu_count() or 2) - 1))
+    o.evaluate_error(True, False, cores)
+    t = time.perf_counter()
+    o.evaluate_error(True, False, cores)
+    t_eval = time.perf_counter() - t
+    t = time.perf_counter()
+    o.build_only(True)
+    t_build = time.perf_counter() - t
+    return dict(value=o.n_terms / (t_eval + t_build), unit="error-terms/s", cores=1, kind="port",
+                sample="first %.1f s of the same workload (%d error terms): buildSystem serial on 1 core as in the reference "
+                       "(%.3f s), evaluateError on %d threads (%.3f s)" % (args.cpu_sample_seconds, o.n_terms, t_build, cores, t_eval),
+                build_terms_per_s=o.n_terms / t_build, evaluate_threads=cores)
+
+
+if __name__ == "__main__":
+    main()

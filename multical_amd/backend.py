@@ -188,6 +188,27 @@ class HipApi(object):
         if s:
             raise BackendError(self.lib.mc_last_error(self.ctx).decode())
 
+    def batch_info(self):
+        out = []
+        for i in range(self.lib.mc_num_batches(self.ctx)):
+            k, n, g = C.c_int(), C.c_int(), C.c_int()
+            self._chk(self.lib.mc_batch_info(self.ctx, i, C.byref(k), C.byref(n), C.byref(g)))
+            out.append((k.value, n.value, g.value))
+        return out
+
+    def batch_counts(self):
+        out = []
+        for i in range(self.lib.mc_num_batches(self.ctx)):
+            a, b, c = C.c_double(), C.c_double(), C.c_double()
+            self._chk(self.lib.mc_batch_counts(self.ctx, i, C.byref(a), C.byref(b), C.byref(c)))
+            out.append((a.value, b.value, c.value))
+        return out
+
+    def build_system_timed(self, use_mest=True, build=True):
+        ms = np.zeros(self.lib.mc_num_batches(self.ctx), np.float32)
+        self._chk(self.lib.mc_build_system_timed(self.ctx, int(use_mest), int(build), ms.ctypes.data_as(C.POINTER(C.c_float))))
+        return ms
+
     def device_info(self):
         name = C.create_string_buffer(256)
         ncu, gib = C.c_int(), C.c_double()

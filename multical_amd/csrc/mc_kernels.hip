@@ -435,7 +435,8 @@ struct mc_context {
   bool have_prev = false;
 
   void uploadStructure();
-  void launchAll(bool build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st);
+  void launchAll(bool build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
+                 std::vector<hipEvent_t>* ev = nullptr);
 };
 
 static thread_local std::string g_create_error;
@@ -550,7 +551,8 @@ void mc_context::uploadStructure() {
   Jpart.alloc(std::max(1, n_jpart));
 }
 
-void mc_context::launchAll(bool build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st) {
+void mc_context::launchAll(bool build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
+                           std::vector<hipEvent_t>* ev) {
   DevCommon dc;
   dc.x = x.p; dc.fp_data = fp_data.p; dc.fp_off = fp_off.p; dc.col_h = col_h.p;
   dc.Cx = dCx; dc.rhs = dRhs; dc.e = dE; dc.chi2 = chi2.p; dc.Jpart = Jpart.p; dc.status = status.p;
@@ -563,6 +565,7 @@ void mc_context::launchAll(bool build, int useM, double* dCx, double* dRhs, doub
   for (size_t i = 0; i < db.size(); ++i) {
     DevBatch& d = *db[i];
     const Batch& b = P.batches[i];
+    if (ev) HIP_CHECK(hipEventRecord((*ev)[i], st));
     if (d.n_groups == 0) continue;
     switch (b.kind) {
       case KIND_REPROJ:
@@ -584,6 +587,7 @@ void mc_context::launchAll(bool build, int useM, double* dCx, double* dRhs, doub
     }
     HIP_CHECK(hipGetLastError());
   }
+  if (ev) HIP_CHECK(hipEventRecord((*ev)[db.size()], st));
   if (!build || dJ) {
     double* out = dJ ? dJ : J.p;
     hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, Jpart.p, n_jpart, out);
@@ -743,6 +747,59 @@ int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double*
   HIP_CHECK(hipStreamSynchronize(0));
   if (Cx_out) HIP_CHECK(hipMemcpy(Cx_out, ctx->Cx.p, sizeof(double) * ctx->P.nnz, hipMemcpyDeviceToHost));
   if (rhs_out) HIP_CHECK(hipMemcpy(rhs_out, ctx->rhs.p, sizeof(double) * ctx->P.j_cols, hipMemcpyDeviceToHost));
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_num_batches(const mc_context* ctx) { return (int)ctx->P.batches.size(); }
+int mc_batch_info(const mc_context* ctx, int batch, int* kind, int* n_terms, int* n_groups) {
+  if (!ctx->P.finalized || batch < 0 || batch >= (int)ctx->P.batches.size()) return -1;
+  const Batch& b = ctx->P.batches[batch];
+  if (kind) *kind = b.kind;
+  if (n_terms) *n_terms = b.n_terms;
+  if (n_groups) *n_groups = ctx->db[batch]->n_groups;
+  return 0;
+}
+// SURVEY.md 8(d) accounting for one batch: algorithmic flops of buildSystem with every structurally present
+// block counted (dense, what the reference computes, padded zero blocks included), the same with only the
+// blocks that can be non-zero (live), and the compulsory record bytes.
+int mc_batch_counts(const mc_context* ctx, int batch, double* flops_dense, double* flops_live, double* record_bytes) {
+  if (!ctx->P.finalized || batch < 0 || batch >= (int)ctx->P.batches.size()) return -1;
+  const Problem& P = ctx->P;
+  const Batch& b = P.batches[batch];
+  static const double fjac[6] = {3500.0, 3500.0, 6000.0, 3000.0, 3000.0, 0.0};
+  static const double rec[6] = {72.0, 72.0, 52.0, 52.0, 64.0, 0.0};
+  double fd = 0, fl = 0;
+  for (const GroupRec& g : b.groups) {
+    double s1 = 0, s2 = 0, l1 = 0, l2 = 0;
+    for (int blk : P.fp_pattern[g.fp]) { double d = P.block_dim[blk]; s1 += d; s2 += d * d; }
+    for (auto& w : P.fp_written[g.fp]) {
+      int n = w[2];
+      if (w[0] == 0 && (b.kind == KIND_REPROJ || b.kind == KIND_LIDAR)) n = std::min(n, 6);  // live support
+      for (int k = 0; k < n; ++k) { double d = P.block_dim[w[1] + k]; l1 += d; l2 += d * d; }
+    }
+    double D = b.dim;
+    fd += g.term_count * (2.0 * D * 0.5 * (s1 * s1 + s2) + 2.0 * D * s1 + fjac[b.kind]);
+    fl += g.term_count * (2.0 * D * 0.5 * (l1 * l1 + l2) + 2.0 * D * l1 + fjac[b.kind]);
+  }
+  if (b.kind == KIND_MOTION) {
+    const SplineRec& sp = P.splines[b.spline];
+    fd = fl = 2.0 * sp.n_coeff * (2 * sp.order - 1) * sp.dim * sp.dim;
+  }
+  if (flops_dense) *flops_dense = fd;
+  if (flops_live) *flops_live = fl;
+  if (record_bytes) *record_bytes = rec[b.kind] * b.n_terms;
+  return 0;
+}
+int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float* ms_per_batch) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  size_t n = ctx->db.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  ctx->launchAll(build != 0, use_mestimator, ctx->Cx.p, ctx->rhs.p, build ? nullptr : ctx->J.p, nullptr, 0, &ev);
+  HIP_CHECK(hipStreamSynchronize(0));
+  for (size_t i = 0; i < n; ++i) HIP_CHECK(hipEventElapsedTime(&ms_per_batch[i], ev[i], ev[i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
   return 0;
   MC_CATCH(ctx, -1)
 }

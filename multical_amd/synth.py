@@ -361,14 +361,18 @@ def build_spec(W, state, meas, unit_weights=False, with_mest=True, with_motion=T
             sp.add_motion_term(h["accel_bias"], np.eye(3) / (3.0e-3 ** 2), 1)
     if cfg.pose_motion_terms and with_motion:
         sp.add_motion_term(H["pose"], np.diag([1e-6] * 3 + [1e-5] * 3), 2)
+    # LiDAR terms are added plane by plane (addLiDARErrorTerms loops `for idx, obs in enumerate(self.targetObs)`,
+    # sensors_and_targets.py:274-305), each plane's inliers in scan order
     for k, lid in enumerate(W["lidars"]):
         h = H["lidars"][k]
-        n = lid["t"].size
         lm = cfg.lidar_mest if (with_mest and cfg.lidar_mest) else (S.MEST_NONE, 0.0)
-        sp.add_lidar_batch(H["pose"], h["toff"], h["q"], h["t"], lid["t"], lid["dir"], meas["lidar"][k],
-                           np.full(n, 1.0 if unit_weights else 1.0 / cfg.lidar_sigma),
-                           [H["boards"][b][0] for b in lid["board"]], [H["boards"][b][1] for b in lid["board"]],
-                           cfg.time_padding, lm[0], lm[1])
+        for b in range(cfg.n_boards):
+            idx = np.nonzero(lid["board"] == b)[0]
+            if idx.size == 0:
+                continue
+            sp.add_lidar_batch(H["pose"], h["toff"], h["q"], h["t"], lid["t"][idx], lid["dir"][idx], meas["lidar"][k][idx],
+                               np.full(idx.size, 1.0 if unit_weights else 1.0 / cfg.lidar_sigma),
+                               [H["boards"][b][0]] * idx.size, [H["boards"][b][1]] * idx.size, cfg.time_padding, lm[0], lm[1])
     return sp, H
 
 
@@ -393,8 +397,10 @@ def synthesize(W, make_api, noise=True):
         meas["accel"][k] = -e[row:row + 3 * n].reshape(n, 3); row += 3 * n   # e_out = -(pred - 0)
         meas["gyro"][k] = -e[row:row + 3 * n].reshape(n, 3); row += 3 * n
     for k, lid in enumerate(W["lidars"]):
-        n = lid["t"].size
-        meas["lidar"][k] = -e[row:row + n].copy(); row += n
+        for b in range(cfg.n_boards):
+            idx = np.nonzero(lid["board"] == b)[0]
+            meas["lidar"][k][idx] = -e[row:row + idx.size]
+            row += idx.size
     assert row == e.size
     if noise:
         for k in range(len(W["cams"])):
