@@ -99,7 +99,7 @@ def main():
     value = n_terms / (dt / args.steps)
 
     # ---- per-kernel timing (HIP events on the launch stream, inside the C ABI) and roofline of the dominant kernel
-    info, counts = api.batch_info(), api.batch_counts()
+    info = api.launch_info()
     reps = max(3, min(10, args.steps))
     ms_build = np.zeros(len(info))
     ms_eval = np.zeros(len(info))
@@ -108,16 +108,12 @@ def main():
         ms_eval += api.build_system_timed(True, False)
     ms_build /= reps
     ms_eval /= reps
-    kind_names = {0: "k_reproj", 1: "k_group<StaticReproj>", 2: "k_group<Imu>", 3: "k_group<Imu>", 4: "k_group<Lidar>", 5: "k_motion"}
     per_kernel = {}
-    for (kind, nt, ng), (fd, fl, rb), mb, me in zip(info, counts, ms_build, ms_eval):
-        d = per_kernel.setdefault(kind_names[kind], dict(ms=0.0, launches=0, flops_dense=0.0, flops_live=0.0, rec_bytes=0.0, terms=0, eval_ms=0.0))
-        if ng == 0:
+    for (name, nbatch, nt, nwg, fd, fl, rb), mb, me in zip(info, ms_build, ms_eval):
+        if nwg == 0:
             continue
-        # this rank's share of the batch
-        share = 1.0 / world if world > 1 else 1.0
-        d["ms"] += mb; d["eval_ms"] += me; d["launches"] += 1
-        d["flops_dense"] += fd * share; d["flops_live"] += fl * share; d["rec_bytes"] += rb * share; d["terms"] += nt * share
+        per_kernel[name] = dict(ms=float(mb), eval_ms=float(me), launches=1, flops_dense=fd, flops_live=fl, rec_bytes=rb,
+                                terms=nt, workgroups=nwg)
     dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
     pk = per_kernel[dom]
     avg_launch_ms = pk["ms"] / max(1, pk["launches"])

@@ -146,17 +146,17 @@ int mc_get_dv_params(mc_context* ctx, int dv, double* out);
 int mc_device_status(mc_context* ctx);
 
 /* Measurement aids.  The reference's phase timers ("Optimizer2: build Hessian", "...evaluate error",
- * aslam_backend/src/Optimizer2.cpp:185-189) are compiled out (Optimizer2.hpp:53-55); these give the same phases per
- * error-term batch: mc_build_system_timed runs one evaluateError (build = 0) or buildSystem (build = 1) on the
- * internal buffers with a HIP event pair around every batch's kernels and writes the milliseconds per batch
- * (mc_num_batches entries, in mc_add_*_batch call order).  mc_batch_info: kind 0 reprojection, 1 static
- * reprojection, 2 accelerometer, 3 gyroscope, 4 lidar, 5 motion. */
-int mc_num_batches(const mc_context* ctx);
-int mc_batch_info(const mc_context* ctx, int batch, int* kind, int* n_terms, int* n_groups);
-int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float* ms_per_batch);
-/* SURVEY.md 8(d) accounting per batch: buildSystem flops with every structurally present block (padded zeros
- * included, as the reference computes them), with the live blocks only, and the compulsory record bytes. */
-int mc_batch_counts(const mc_context* ctx, int batch, double* flops_dense, double* flops_live, double* record_bytes);
+ * aslam_backend/src/Optimizer2.cpp:185-189) are compiled out (Optimizer2.hpp:53-55).  Here every term family is ONE
+ * kernel launch shared by all its batches: launch 0 reprojection (F1), 1 static reprojection (F2), 2 IMU (F3 + F4),
+ * 3 lidar (F5), 4 motion (F7).  mc_build_system_timed runs one evaluateError (build = 0) or buildSystem (build = 1)
+ * on the internal buffers with a HIP event pair around every launch and writes mc_num_launches() milliseconds.
+ * mc_launch_counts: SURVEY.md 8(d) accounting of this rank's share -- buildSystem flops with every structurally
+ * present block (padded zeros included, as the reference computes them), with the live blocks only, and the
+ * compulsory record bytes. */
+int mc_num_launches(const mc_context* ctx);
+int mc_launch_info(const mc_context* ctx, int launch, int* n_batches, int* n_terms, int* n_workgroups);
+int mc_launch_counts(const mc_context* ctx, int launch, double* flops_dense, double* flops_live, double* record_bytes);
+int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float* ms_per_launch);
 
 /* number of multiprocessors etc. for reports; returns 0 and fills what it can */
 int mc_device_info(mc_context* ctx, char* name, int name_len, int* n_cu, double* hbm_gib);

@@ -47,9 +47,9 @@ SIGNATURES = {
     "mc_revert_update": (C.c_int, [_ctx]),
     "mc_get_dv_params": (C.c_int, [_ctx, C.c_int, _dp]),
     "mc_device_status": (C.c_int, [_ctx]),
-    "mc_num_batches": (C.c_int, [_ctx]),
-    "mc_batch_info": (C.c_int, [_ctx, C.c_int, _ip, _ip, _ip]),
-    "mc_batch_counts": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
+    "mc_num_launches": (C.c_int, [_ctx]),
+    "mc_launch_info": (C.c_int, [_ctx, C.c_int, _ip, _ip, _ip]),
+    "mc_launch_counts": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
     "mc_build_system_timed": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mc_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, _ip, _dp]),
 }

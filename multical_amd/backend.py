@@ -188,24 +188,21 @@ class HipApi(object):
         if s:
             raise BackendError(self.lib.mc_last_error(self.ctx).decode())
 
-    def batch_info(self):
-        out = []
-        for i in range(self.lib.mc_num_batches(self.ctx)):
-            k, n, g = C.c_int(), C.c_int(), C.c_int()
-            self._chk(self.lib.mc_batch_info(self.ctx, i, C.byref(k), C.byref(n), C.byref(g)))
-            out.append((k.value, n.value, g.value))
-        return out
+    LAUNCH_NAMES = ("k_reproj", "k_group<StaticReproj>", "k_stream<Imu>", "k_stream<Lidar>", "k_motion")
 
-    def batch_counts(self):
+    def launch_info(self):
+        """[(kernel name, batches, terms, workgroups, flops_dense, flops_live, record_bytes)] per kernel launch of a build"""
         out = []
-        for i in range(self.lib.mc_num_batches(self.ctx)):
+        for i in range(self.lib.mc_num_launches(self.ctx)):
+            nb, n, g = C.c_int(), C.c_int(), C.c_int()
             a, b, c = C.c_double(), C.c_double(), C.c_double()
-            self._chk(self.lib.mc_batch_counts(self.ctx, i, C.byref(a), C.byref(b), C.byref(c)))
-            out.append((a.value, b.value, c.value))
+            self._chk(self.lib.mc_launch_info(self.ctx, i, C.byref(nb), C.byref(n), C.byref(g)))
+            self._chk(self.lib.mc_launch_counts(self.ctx, i, C.byref(a), C.byref(b), C.byref(c)))
+            out.append((self.LAUNCH_NAMES[i], nb.value, n.value, g.value, a.value, b.value, c.value))
         return out
 
     def build_system_timed(self, use_mest=True, build=True):
-        ms = np.zeros(self.lib.mc_num_batches(self.ctx), np.float32)
+        ms = np.zeros(self.lib.mc_num_launches(self.ctx), np.float32)
         self._chk(self.lib.mc_build_system_timed(self.ctx, int(use_mest), int(build), ms.ctypes.data_as(C.POINTER(C.c_float))))
         return ms
 

@@ -43,6 +43,17 @@ struct GroupRec {
   int term_first, term_count;
   int fp;    // footprint id
   int aux;   // kind specific (F1: observation index)
+  int batch; // index into the launch's view array (set when the launch list is built)
+};
+
+// A chunk = consecutive (time-sorted) terms of one stream batch (lidar, accelerometer, gyroscope) handled by one
+// workgroup: their live pose-coefficient windows lie inside the coefficient range [pose_lo, pose_lo + pose_nb) and
+// they share the list of other blocks `ofp` (extrinsics, time offset, board pose, bias-coefficient window...).
+struct ChunkRec {
+  int term_first, term_count;  // positions in the batch's time-sorted `order`
+  int pose_lo, pose_nb;        // coefficient range laid out for the chunk (0 blocks if the pose spline is inactive)
+  int ofp;                     // "other blocks" footprint id
+  int batch;                   // index into the launch's view array (set when the launch list is built)
 };
 
 struct Batch {
@@ -64,7 +75,22 @@ struct Batch {
   std::vector<GroupRec> groups;       // all groups (terms numbered within the batch)
   std::vector<GroupRec> my_groups;    // the groups of this rank's time window
   std::vector<double> group_time;     // representative time per group (for sharding)
+  // stream kinds (lidar / IMU): time-sorted order, per-term frozen coefficient buffer, chunks
+  std::vector<int> order, term_lo, term_nbuf;
+  std::vector<ChunkRec> chunks, my_chunks;
+  std::vector<double> chunk_time;
+  int max_nb = 0, max_nob = 0, max_g = 0, max_terms = 0;   // over my_chunks: sizes the kernel's LDS
+  // SURVEY 8(d) accounting (filled by finalize)
+  double flops_dense = 0, flops_live = 0;
 };
+
+// "other blocks" footprint layout in `ofp_data` at ofp_off[f]:
+//   [0] n blocks  [1] G (local columns)  [2] first buffered bias coefficient  [3] number of buffered bias coefficients
+//   [4 .. 4+MC_MAX_ROLES) role -> local column (-1: inactive)
+//   then n x (block index, dim, local column start, global column base)
+enum { OFP_HDR = 4 + MC_MAX_ROLES };
+// chunking limits: terms per chunk (rows must fit the LDS tile) and the target coefficient window
+enum { CHUNK_TERMS_LIDAR = 128, CHUNK_TERMS_IMU = 32, CHUNK_WINDOW = 40, CHUNK_BIAS_WINDOW = 8 };
 
 // footprint layout in the flat int array `fp_data` at fp_off[f]:
 //   [0] nb   [1] C (local columns)   [2] first buffered spline coefficient, [3] number of buffered coefficients (time-offset kinds)
@@ -95,6 +121,9 @@ struct Problem {
   std::vector<int> fp_data, fp_off;
   std::unordered_map<std::string, int> fp_lookup;
   std::vector<int> update_dvs;              // active dvs in block order
+  std::vector<int> ofp_data, ofp_off;       // other-block footprints of the chunks
+  std::map<std::vector<int>, int> ofp_lookup;
+  std::vector<int> pat_colptr, pat_rows, pat_roff, pat_cp0;   // block pattern as CSR for device-side slot lookups
 
   // ------------------------------------------------------------------ description
   int addDv(int kind, const double* params, int n, int active, double scaling) {
@@ -264,6 +293,43 @@ struct Problem {
     fp_nbuf.push_back(nBuf);
     return id;
   }
+  // Other-block footprint of a chunk.  `written` = (role, first block, n blocks), blocks of one role consecutive.
+  int internOtherFootprint(const std::vector<std::array<int, 3>>& written, int biasLo, int biasNbuf) {
+    std::vector<int> key;
+    key.push_back(biasLo); key.push_back(biasNbuf);
+    for (auto& w : written) { key.push_back(w[0]); key.push_back(w[1]); key.push_back(w[2]); }
+    auto it = ofp_lookup.find(key);
+    if (it != ofp_lookup.end()) return it->second;
+    int id = (int)ofp_off.size();
+    ofp_lookup.emplace(std::move(key), id);
+    ofp_off.push_back((int)ofp_data.size());
+    std::vector<int> rolecol(MC_MAX_ROLES, -1);
+    int nb = 0, G = 0;
+    for (auto& w : written) { rolecol[w[0]] = G; for (int k = 0; k < w[2]; ++k) { G += block_dim[w[1] + k]; ++nb; } }
+    ofp_data.push_back(nb); ofp_data.push_back(G); ofp_data.push_back(biasLo); ofp_data.push_back(biasNbuf);
+    for (int r = 0; r < MC_MAX_ROLES; ++r) ofp_data.push_back(rolecol[r]);
+    int c = 0;
+    for (auto& w : written)
+      for (int k = 0; k < w[2]; ++k) {
+        int blkid = w[1] + k;
+        ofp_data.push_back(blkid); ofp_data.push_back(block_dim[blkid]); ofp_data.push_back(c); ofp_data.push_back(block_col[blkid]);
+        c += block_dim[blkid];
+      }
+    return id;
+  }
+  // pattern cliques of the stream kinds: (first coefficient block, count, second range first, count, other blocks...)
+  std::map<std::vector<int>, int> clique_lookup;
+  std::vector<std::vector<int>> cliques;
+  void addClique(std::vector<int>& blocks) {
+    auto it = clique_lookup.find(blocks);
+    if (it != clique_lookup.end()) return;
+    clique_lookup.emplace(blocks, (int)cliques.size());
+    std::vector<int> sorted = blocks;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+      throw std::invalid_argument("a design variable plays two roles in one error term");
+    cliques.push_back(std::move(sorted));
+  }
   std::vector<int> fp_coef_lo, fp_nbuf;
   std::vector<std::vector<int>> fp_pattern;
   std::vector<std::vector<std::array<int, 3>>> fp_written;
@@ -294,23 +360,19 @@ inline void Problem::finalize() {
     b.groups.clear(); b.group_time.clear();
     auto pushGroup = [&](int first, int count, int fp, int aux, double time, int maxTerms) {
       for (int o = 0; o < count; o += maxTerms) {
-        b.groups.push_back(GroupRec{first + o, std::min(maxTerms, count - o), fp, aux});
+        b.groups.push_back(GroupRec{first + o, std::min(maxTerms, count - o), fp, aux, 0});
         b.group_time.push_back(time);
       }
     };
-    if (b.kind == KIND_REPROJ || b.kind == KIND_LIDAR) {
+    if (b.kind == KIND_REPROJ) {
       const SplineRec& s = splines[b.spline];
       int coef_block0 = dvs[s.first_dv].block;  // -1 if the spline is inactive
-      bool reproj = b.kind == KIND_REPROJ;
-      int n_units = reproj ? (int)b.obs_first.size() - 1 : b.n_terms;
-      int run_first = -1, run_fp = -1, run_count = 0;
-      double run_time = 0;
+      int n_units = (int)b.obs_first.size() - 1;
       for (int u = 0; u < n_units; ++u) {
         double t0 = b.t[u] + (b.dv[2] >= 0 ? x[dvs[b.dv[2]].off] : 0.0);
         int lo, hi;
         timeOffsetBuffer(s, t0, b.pad, lo, hi);
-        int seg = segmentOf(s, t0);
-        int dq = reproj ? b.obs_dv_q[u] : b.term_dv_q[u], dt = reproj ? b.obs_dv_t[u] : b.term_dv_t[u];
+        int dq = b.obs_dv_q[u], dt = b.obs_dv_t[u];
         std::vector<int> pattern;
         std::vector<std::array<int, 3>> written;
         if (coef_block0 >= 0) {
@@ -318,7 +380,6 @@ inline void Problem::finalize() {
           // and the kernel places the 6 live coefficient blocks inside it at run time
           for (int c = lo; c <= hi; ++c) pattern.push_back(coef_block0 + c);
           written.push_back({0, coef_block0 + lo, hi - lo + 1});
-          (void)seg;
         }
         int gl[5] = {b.dv[0], b.dv[1], dq, dt, b.dv[2]};  // q_x_b, t_x_b, q_p_w, t_p_w, time offset
         for (int g = 0; g < 5; ++g)
@@ -327,53 +388,103 @@ inline void Problem::finalize() {
         if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
           throw std::invalid_argument("a design variable plays two roles in one error term");
         int fp = internFootprint(pattern, written, lo, coef_block0 >= 0 ? hi - lo + 1 : 0);
-        if (reproj) {
-          pushGroup(b.obs_first[u], b.obs_first[u + 1] - b.obs_first[u], fp, u, b.t[u], 1 << 30);
-        } else {
-          // consecutive lidar points with the same footprint form one group (<= 48 terms)
-          if (run_count > 0 && (fp != run_fp || run_count == 48)) { pushGroup(run_first, run_count, run_fp, 0, run_time, 48); run_count = 0; }
-          if (run_count == 0) { run_first = u; run_fp = fp; run_time = b.t[u]; }
-          ++run_count;
-        }
+        pushGroup(b.obs_first[u], b.obs_first[u + 1] - b.obs_first[u], fp, u, b.t[u], 1 << 30);
       }
-      if (!reproj && run_count > 0) pushGroup(run_first, run_count, run_fp, 0, run_time, 48);
-    } else if (b.kind == KIND_ACCEL || b.kind == KIND_GYRO) {
+    } else if (b.kind == KIND_LIDAR || b.kind == KIND_ACCEL || b.kind == KIND_GYRO) {
+      const bool lidar = b.kind == KIND_LIDAR;
       const SplineRec& s = splines[b.spline];
-      int coef_block0 = dvs[s.first_dv].block;
-      int run_first = -1, run_fp = -1, run_count = 0;
-      double run_time = 0;
-      for (int u = 0; u < b.n_terms; ++u) {
-        double t = b.t[u];
-        if (!(t >= s.t_min && t <= s.t_max)) throw std::invalid_argument("measurement time outside the pose spline");
-        int seg = segmentOf(s, t);
-        std::vector<int> pattern;
-        std::vector<std::array<int, 3>> written;
-        if (coef_block0 >= 0) {
-          for (int c = 0; c < s.order; ++c) pattern.push_back(coef_block0 + seg + c);
-          written.push_back({IMU_ROLE_POSE, coef_block0 + seg, s.order});
-        }
-        if (b.bias_spline >= 0) {
-          const SplineRec& bs = splines[b.bias_spline];
-          if (!(t >= bs.t_min && t <= bs.t_max)) throw std::invalid_argument("measurement time outside the bias spline");
-          int bb0 = dvs[bs.first_dv].block;
-          if (bb0 >= 0) {
-            int bseg = segmentOf(bs, t);
-            for (int c = 0; c < bs.order; ++c) pattern.push_back(bb0 + bseg + c);
-            written.push_back({IMU_ROLE_BIAS, bb0 + bseg, bs.order});
-          }
-        } else if (blk(b.dv[0]) >= 0) { pattern.push_back(blk(b.dv[0])); written.push_back({IMU_ROLE_BIAS, blk(b.dv[0]), 1}); }
-        if (b.kind == KIND_ACCEL && blk(b.dv[1]) >= 0) { pattern.push_back(blk(b.dv[1])); written.push_back({IMU_ROLE_G, blk(b.dv[1]), 1}); }
-        if (blk(b.dv[2]) >= 0) { pattern.push_back(blk(b.dv[2])); written.push_back({IMU_ROLE_QIB, blk(b.dv[2]), 1}); }
-        if (b.kind == KIND_ACCEL && blk(b.dv[3]) >= 0) { pattern.push_back(blk(b.dv[3])); written.push_back({IMU_ROLE_RB, blk(b.dv[3]), 1}); }
-        std::sort(pattern.begin(), pattern.end());
-        if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
-          throw std::invalid_argument("a design variable plays two roles in one error term");
-        int fp = internFootprint(pattern, written);
-        if (run_count > 0 && (fp != run_fp || run_count == 16)) { pushGroup(run_first, run_count, run_fp, 0, run_time, 16); run_count = 0; }
-        if (run_count == 0) { run_first = u; run_fp = fp; run_time = t; }
-        ++run_count;
+      const int coef_block0 = dvs[s.first_dv].block;
+      const int n = b.n_terms;
+      b.order.resize(n);
+      std::iota(b.order.begin(), b.order.end(), 0);
+      if (!std::is_sorted(b.t.begin(), b.t.end()))
+        std::stable_sort(b.order.begin(), b.order.end(), [&](int a, int c) { return b.t[a] < b.t[c]; });
+      b.term_lo.assign(n, 0); b.term_nbuf.assign(n, 0);
+      b.chunks.clear(); b.chunk_time.clear();
+      b.flops_dense = b.flops_live = 0;
+      const SplineRec* bs = (!lidar && b.bias_spline >= 0) ? &splines[b.bias_spline] : nullptr;
+      const int bias_block0 = bs ? dvs[bs->first_dv].block : -1;
+      const int maxTerms = lidar ? (int)CHUNK_TERMS_LIDAR : (int)CHUNK_TERMS_IMU;
+      // batch-level other roles
+      std::vector<std::pair<int, int>> fixedRoles;  // (role, dv)
+      if (lidar) fixedRoles = {{F5_ROLE_QLB, b.dv[0]}, {F5_ROLE_TLB, b.dv[1]}, {F5_ROLE_TOFF, b.dv[2]}};
+      else {
+        if (!bs) fixedRoles.push_back({IMU_ROLE_BIAS, b.dv[0]});
+        if (b.kind == KIND_ACCEL) fixedRoles.push_back({IMU_ROLE_G, b.dv[1]});
+        fixedRoles.push_back({IMU_ROLE_QIB, b.dv[2]});
+        if (b.kind == KIND_ACCEL) fixedRoles.push_back({IMU_ROLE_RB, b.dv[3]});
       }
-      if (run_count > 0) pushGroup(run_first, run_count, run_fp, 0, run_time, 16);
+      double fixed_s1 = 0, fixed_s2 = 0;
+      for (auto& fr : fixedRoles) if (blk(fr.second) >= 0) { double d = dvs[fr.second].dim; fixed_s1 += d; fixed_s2 += d * d; }
+      const double fjac = lidar ? 3000.0 : (b.kind == KIND_ACCEL ? 6000.0 : 3000.0);
+      int c_first = 0, c_count = 0, c_lo = 0, c_hi = -1, c_blo = 0, c_bhi = -1, c_q = -1, c_t = -1;
+      double c_time = 0;
+      auto closeChunk = [&]() {
+        if (c_count == 0) return;
+        std::vector<std::array<int, 3>> written;
+        int biasLo = 0, biasN = 0;
+        if (bs && bias_block0 >= 0) { biasLo = c_blo; biasN = c_bhi - c_blo + 1; written.push_back({IMU_ROLE_BIAS, bias_block0 + c_blo, biasN}); }
+        for (auto& fr : fixedRoles) if (blk(fr.second) >= 0) written.push_back({fr.first, blk(fr.second), 1});
+        if (lidar) {
+          if (blk(c_q) >= 0) written.push_back({F5_ROLE_QPW, blk(c_q), 1});
+          if (blk(c_t) >= 0) written.push_back({F5_ROLE_TPW, blk(c_t), 1});
+        }
+        int ofp = internOtherFootprint(written, biasLo, biasN);
+        bool poseActive = coef_block0 >= 0;
+        b.chunks.push_back(ChunkRec{c_first, c_count, poseActive ? c_lo : 0, poseActive ? c_hi - c_lo + 1 : 0, ofp, 0});
+        b.chunk_time.push_back(c_time);
+        c_count = 0;
+      };
+      int last_key[6] = {-2, -2, -2, -2, -2, -2};
+      for (int pos = 0; pos < n; ++pos) {
+        const int u = b.order[pos];
+        int lo, hi;
+        if (lidar) {
+          double t0 = b.t[u] + (b.dv[2] >= 0 ? x[dvs[b.dv[2]].off] : 0.0);
+          timeOffsetBuffer(s, t0, b.pad, lo, hi);
+        } else {
+          if (!(b.t[u] >= s.t_min && b.t[u] <= s.t_max)) throw std::invalid_argument("measurement time outside the pose spline");
+          lo = segmentOf(s, b.t[u]); hi = lo + s.order - 1;
+        }
+        b.term_lo[u] = lo; b.term_nbuf[u] = hi - lo + 1;
+        int blo = 0, bhi = -1;
+        if (bs) {
+          if (!(b.t[u] >= bs->t_min && b.t[u] <= bs->t_max)) throw std::invalid_argument("measurement time outside the bias spline");
+          blo = segmentOf(*bs, b.t[u]); bhi = blo + bs->order - 1;
+        }
+        const int q = lidar ? b.term_dv_q[u] : -1, tt = lidar ? b.term_dv_t[u] : -1;
+        // pattern clique of this term (every block of its design-variable set, padded buffer included)
+        int key[6] = {lo, hi, blo, bhi, q, tt};
+        if (std::memcmp(key, last_key, sizeof key) != 0) {
+          std::memcpy(last_key, key, sizeof key);
+          std::vector<int> clique;
+          if (coef_block0 >= 0) for (int c = lo; c <= hi; ++c) clique.push_back(coef_block0 + c);
+          if (bs && bias_block0 >= 0) for (int c = blo; c <= bhi; ++c) clique.push_back(bias_block0 + c);
+          for (auto& fr : fixedRoles) if (blk(fr.second) >= 0) clique.push_back(blk(fr.second));
+          if (lidar) { if (blk(q) >= 0) clique.push_back(blk(q)); if (blk(tt) >= 0) clique.push_back(blk(tt)); }
+          addClique(clique);
+        }
+        {  // SURVEY 8(d) flops of this term: dense = whole clique, live = the 6 live coefficient blocks
+          double s1 = fixed_s1, s2 = fixed_s2, l1, l2;
+          if (lidar) { if (blk(q) >= 0) { s1 += 3; s2 += 9; } if (blk(tt) >= 0) { s1 += 3; s2 += 9; } }
+          if (bs && bias_block0 >= 0) { s1 += 3.0 * (bhi - blo + 1); s2 += 9.0 * (bhi - blo + 1); }
+          l1 = s1; l2 = s2;
+          if (coef_block0 >= 0) { s1 += 6.0 * (hi - lo + 1); s2 += 36.0 * (hi - lo + 1); l1 += 36.0; l2 += 216.0; }
+          double D = b.dim;
+          b.flops_dense += 2.0 * D * 0.5 * (s1 * s1 + s2) + 2.0 * D * s1 + fjac;
+          b.flops_live += 2.0 * D * 0.5 * (l1 * l1 + l2) + 2.0 * D * l1 + fjac;
+        }
+        if (c_count > 0) {
+          int nlo = std::min(c_lo, lo), nhi = std::max(c_hi, hi), nblo = std::min(c_blo, blo), nbhi = std::max(c_bhi, bhi);
+          bool fits = c_count < maxTerms && (nhi - nlo + 1 <= std::max((int)CHUNK_WINDOW, hi - lo + 1)) &&
+                      (!bs || nbhi - nblo + 1 <= (int)CHUNK_BIAS_WINDOW) && q == c_q && tt == c_t;
+          if (fits) { c_lo = nlo; c_hi = nhi; c_blo = nblo; c_bhi = nbhi; }
+          else closeChunk();
+        }
+        if (c_count == 0) { c_first = pos; c_lo = lo; c_hi = hi; c_blo = blo; c_bhi = bhi; c_q = q; c_t = tt; c_time = b.t[u]; }
+        ++c_count;
+      }
+      closeChunk();
     } else if (b.kind == KIND_STATIC_REPROJ) {
       int n_obs = (int)b.obs_first.size() - 1;
       const CameraRec& c = cams[b.cam];
@@ -399,6 +510,9 @@ inline void Problem::finalize() {
   col_rows.assign(n_blocks, std::vector<int>());
   for (int i = 0; i < n_blocks; ++i) col_rows[i].push_back(i);
   for (const std::vector<int>& pat : fp_pattern)
+    for (size_t j = 0; j < pat.size(); ++j)
+      for (size_t i = 0; i < j; ++i) col_rows[pat[j]].push_back(pat[i]);
+  for (const std::vector<int>& pat : cliques)
     for (size_t j = 0; j < pat.size(); ++j)
       for (size_t i = 0; i < j; ++i) col_rows[pat[j]].push_back(pat[i]);
   // motion terms: band blocks between active coefficients (BSplineMotionError.hpp:122-156)
@@ -439,6 +553,14 @@ inline void Problem::finalize() {
         for (int r = 0; r < n; ++r) *ci++ = block_col[rb] + r;
       }
     }
+  // ---- block pattern as CSR (device-side slot lookups of the chunk kernels)
+  pat_colptr.assign(n_blocks + 1, 0); pat_rows.clear(); pat_roff.clear(); pat_cp0.assign(n_blocks, 0);
+  for (int c = 0; c < n_blocks; ++c) {
+    pat_cp0[c] = Cp[block_col[c]];
+    pat_rows.insert(pat_rows.end(), col_rows[c].begin(), col_rows[c].end());
+    pat_roff.insert(pat_roff.end(), col_roff[c].begin(), col_roff[c].end());
+    pat_colptr[c + 1] = (int)pat_rows.size();
+  }
   // ---- footprint tables
   auto slotBase = [&](int rb, int cb) {
     const std::vector<int>& rows = col_rows[cb];
@@ -478,11 +600,11 @@ inline void Problem::finalize() {
   {
     struct GT { double t; double cost; };
     std::vector<GT> all;
-    for (const Batch& b : batches)
-      for (size_t g = 0; g < b.groups.size(); ++g) {
-        double per = b.kind == KIND_REPROJ ? 1.0 : (b.kind == KIND_LIDAR ? 1.5 : (b.kind == KIND_STATIC_REPROJ ? 1.0 : 4.0));
-        all.push_back(GT{b.group_time[g], 8.0 + per * b.groups[g].term_count});
-      }
+    for (const Batch& b : batches) {
+      double per = b.kind == KIND_REPROJ ? 1.0 : (b.kind == KIND_LIDAR ? 1.5 : (b.kind == KIND_STATIC_REPROJ ? 1.0 : 4.0));
+      for (size_t g = 0; g < b.groups.size(); ++g) all.push_back(GT{b.group_time[g], 8.0 + per * b.groups[g].term_count});
+      for (size_t g = 0; g < b.chunks.size(); ++g) all.push_back(GT{b.chunk_time[g], 8.0 + per * b.chunks[g].term_count});
+    }
     std::vector<double> cuts(world + 1, 0.0);
     cuts[0] = -INFINITY; cuts[world] = INFINITY;
     if (world > 1 && !all.empty()) {
@@ -504,6 +626,17 @@ inline void Problem::finalize() {
       for (size_t g = 0; g < b.groups.size(); ++g)
         if (b.group_time[g] >= shard_lo && b.group_time[g] < shard_hi) mine.push_back(b.groups[g]);
       b.my_groups.swap(mine);
+      b.my_chunks.clear();
+      b.max_nb = b.max_nob = b.max_g = b.max_terms = 0;
+      for (size_t g = 0; g < b.chunks.size(); ++g)
+        if (b.chunk_time[g] >= shard_lo && b.chunk_time[g] < shard_hi) {
+          const ChunkRec& c = b.chunks[g];
+          b.my_chunks.push_back(c);
+          b.max_nb = std::max(b.max_nb, c.pose_nb);
+          b.max_nob = std::max(b.max_nob, ofp_data[ofp_off[c.ofp]]);
+          b.max_g = std::max(b.max_g, ofp_data[ofp_off[c.ofp] + 1]);
+          b.max_terms = std::max(b.max_terms, c.term_count);
+        }
     }
   }
   update_dvs = block_dv;

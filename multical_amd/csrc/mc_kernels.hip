@@ -23,13 +23,19 @@ namespace mc {
     if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
-enum { STATUS_TIME_OUT_OF_SPLINE = 1, STATUS_BUFFER_EXCEEDED = 2 };
+enum { STATUS_TIME_OUT_OF_SPLINE = 1, STATUS_BUFFER_EXCEEDED = 2, STATUS_INTERNAL = 4 };
 
 struct DevCommon {
   const double* x;
   const int* fp_data;
   const int* fp_off;
   const int* col_h;
+  const int* ofp_data;   // other-block footprints of the chunk kernels
+  const int* ofp_off;
+  const int* pat_colptr; // block pattern (CSR by block column): row blocks, scalar row offsets, first value of the column
+  const int* pat_rows;
+  const int* pat_roff;
+  const int* pat_cp0;
   double* Cx;
   double* rhs;
   double* e;        // may be null
@@ -83,16 +89,24 @@ __device__ __forceinline__ int global_col(const FpView& f, int ca) {
 // per-corner work is a 2 x 19 "core" row pair; the wave reduces the 20 x 20 core Gram matrix (column 19 is
 // the weighted residual) and expands it to the 6 live coefficient blocks with the basis weights.
 enum { F1_LD = F1_CORE + 2 };  // 21: odd stride, conflict-free column reads
-__global__ __launch_bounds__(64) void k_reproj(ReprojBatchView b, DevCommon dc, const GroupRec* __restrict__ groups,
-                                               int jpart_base) {
+__global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
+                                               const GroupRec* __restrict__ groups, int jpart_base) {
   __shared__ double rows[128 * F1_LD];
   __shared__ double Msh[210];
   __shared__ int glc[13], gk[13];
   __shared__ int nglob;
   const int lane = threadIdx.x;
   const GroupRec gr = groups[blockIdx.x];
-  F1Common cm;
-  f1_common(b, dc.x, gr.aux, cm);
+  const ReprojBatchView b = views[gr.batch];
+  // the per-image quantities (spline sample, transformation chain prefix) are wave-uniform: computed once, parked in
+  // LDS and read back by broadcast so they do not occupy ~190 vector registers per lane
+  __shared__ F1Common cm;
+  {
+    F1Common tmp;
+    f1_common(b, dc.x, gr.aux, tmp);
+    if (lane == 0) cm = tmp;
+  }
+  __syncthreads();
   if (!cm.ok) {
     if (lane == 0) { atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
     return;
@@ -200,15 +214,6 @@ __global__ __launch_bounds__(64) void k_reproj(ReprojBatchView b, DevCommon dc, 
 // Generic group kernel: lanes 0..count-1 evaluate one term each into an LDS row tile (D rows per term,
 // C+1 columns, the last one the weighted residual); the wave then forms the group's J^T J / J^T e.
 template <class View> struct TermTraits;
-template <> struct TermTraits<ImuBatchView> {
-  enum { D = 3 };
-  static __device__ __forceinline__ bool eval(const ImuBatchView& b, const double* x, int k, bool useM, bool wantJ,
-                                              const FpView& f, double* J, int ld, double* e, TermOut& out, int* st) {
-    bool ok = imu_term(b, x, k, useM, wantJ, f.rolecol, J, ld, e, out);
-    if (!ok) *st = STATUS_TIME_OUT_OF_SPLINE;
-    return ok;
-  }
-};
 template <> struct TermTraits<StaticReprojBatchView> {
   enum { D = 2 };
   static __device__ __forceinline__ bool eval(const StaticReprojBatchView& b, const double* x, int k, bool useM, bool wantJ,
@@ -216,35 +221,259 @@ template <> struct TermTraits<StaticReprojBatchView> {
     return f2_term(b, x, k, useM, wantJ, f.rolecol, J, ld, e, out);
   }
 };
-template <> struct TermTraits<LidarBatchView> {
+
+__device__ __forceinline__ int b_pose_first_block(const LidarBatchView& b) { return b.sp.first_block; }
+__device__ __forceinline__ int b_pose_first_col(const LidarBatchView& b) { return b.sp.first_col; }
+__device__ __forceinline__ int b_pose_first_block(const ImuBatchView& b) { return b.pose.first_block; }
+__device__ __forceinline__ int b_pose_first_col(const ImuBatchView& b) { return b.pose.first_col; }
+
+// ---------------------------------------------------------------------------------------------
+// Stream kernel (F3 / F4 / F5): one 256-thread workgroup per *chunk* of consecutive time-sorted terms.
+//   phase 0  value-array offsets of every block pair the chunk can touch, looked up once in the block pattern -> LDS
+//   phase 1  thread = term: closed-form residual + Jacobian into a *compact* LDS row
+//            [ 6 live pose-coefficient blocks (36) | the chunk's other columns (G) | residual ], plus beta0 = position
+//            of the live window inside the chunk's coefficient range
+//   phase 2  thread = Hessian entry of the chunk window: gathers sum_k J_k[:,a] J_k[:,b] over the terms whose live
+//            window covers both columns (terms are time sorted, so those are a contiguous run) and issues ONE fp64
+//            atomic per entry; entries are enumerated down the CCS columns so a wave's adds are contiguous runs.
+// Compared with one group per footprint this cuts the atomics by the number of terms that share a window and keeps
+// every lane busy in both phases.
+struct StreamDims { int maxT, maxNb, maxNob, maxG, ld; };
+template <class View> struct StreamBatch {
+  View v;
+  const int* order;      // time-sorted term order of the batch
+  const int* term_lo;    // per term: first coefficient of the buffer frozen at construction, and its length
+  const int* term_nbuf;
+};
+
+__device__ __forceinline__ int slot_lookup(const DevCommon& dc, int rb, int cb) {
+  int lo = dc.pat_colptr[cb], end = dc.pat_colptr[cb + 1], hi = end;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (dc.pat_rows[mid] < rb) lo = mid + 1; else hi = mid;
+  }
+  return (lo < end && dc.pat_rows[lo] == rb) ? dc.pat_cp0[cb] + dc.pat_roff[lo] : -1;
+}
+
+template <class View> struct StreamTraits;
+template <> struct StreamTraits<LidarBatchView> {
   enum { D = 1 };
-  static __device__ __forceinline__ bool eval(const LidarBatchView& b, const double* x, int k, bool useM, bool wantJ,
-                                              const FpView& f, double* J, int ld, double* e, TermOut& out, int* st) {
-    // place the live coefficient window inside the frozen buffer; the term writes at rolecol[0] + 6*(seg - lo)
+  // returns beta0 (>= 0) or -1 after setting *st
+  static __device__ __forceinline__ int eval(const LidarBatchView& b, const double* x, int u, bool useM, bool wantJ,
+                                             const int* of, int pose_lo, int pose_nb, int term_lo, int term_nbuf,
+                                             double* J, int ld, double* e, TermOut& out, int* st) {
     int rc[MC_MAX_ROLES];
 #pragma unroll
-    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = f.rolecol[r];
-    if (rc[F5_ROLE_COEF] >= 0) {
-      double t = b.t[k] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
-      if (!(t >= b.sp.t_min && t <= b.sp.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return false; }
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? 36 + of[4 + r] : -1;
+    int beta0 = 0;
+    rc[F5_ROLE_COEF] = -1;
+    if (pose_nb > 0) {
+      double t = b.t[u] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
+      if (!(t >= b.sp.t_min && t <= b.sp.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
       int seg = spline_segment(b.sp, t);
-      int shift = seg - f.coef_lo;
-      int c0 = rc[F5_ROLE_COEF] + 6 * shift;
-      if (shift < 0 || shift + S6 > f.nbuf) { *st = STATUS_BUFFER_EXCEEDED; return false; }
-      rc[F5_ROLE_COEF] = c0;
+      int shift = seg - term_lo;  // live support must stay inside the buffer frozen at construction (BSplineExpressions.cpp:447)
+      if (shift < 0 || shift + S6 > term_nbuf) { *st = STATUS_BUFFER_EXCEEDED; return -1; }
+      beta0 = seg - pose_lo;
+      rc[F5_ROLE_COEF] = 0;
     }
-    bool ok = f5_term(b, x, k, useM, wantJ, rc, J, ld, e, out);
-    if (!ok) *st = STATUS_TIME_OUT_OF_SPLINE;
-    return ok;
+    if (!f5_term(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    return beta0;
+  }
+};
+template <> struct StreamTraits<ImuBatchView> {
+  enum { D = 3 };
+  static __device__ __forceinline__ int eval(const ImuBatchView& b, const double* x, int u, bool useM, bool wantJ,
+                                             const int* of, int pose_lo, int pose_nb, int, int,
+                                             double* J, int ld, double* e, TermOut& out, int* st) {
+    int rc[MC_MAX_ROLES];
+#pragma unroll
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? 36 + of[4 + r] : -1;
+    const double t = b.t[u];
+    if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    int beta0 = 0;
+    rc[IMU_ROLE_POSE] = -1;
+    if (pose_nb > 0) { beta0 = spline_segment(b.pose, t) - pose_lo; rc[IMU_ROLE_POSE] = 0; }
+    if (b.bias.order > 0 && rc[IMU_ROLE_BIAS] >= 0) {
+      if (!(t >= b.bias.t_min && t <= b.bias.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+      rc[IMU_ROLE_BIAS] += 3 * (spline_segment(b.bias, t) - of[2]);
+    }
+    if (!imu_term(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    return beta0;
   }
 };
 
 template <class View>
-__global__ __launch_bounds__(64) void k_group(View b, DevCommon dc, const GroupRec* __restrict__ groups, int jpart_base) {
+__global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
+                                                const ChunkRec* __restrict__ chunks, StreamDims dm, int jpart_base) {
+  extern __shared__ double smem[];
+  constexpr int D = StreamTraits<View>::D;
+  const int tid = threadIdx.x;
+  const ChunkRec ch = chunks[blockIdx.x];
+  const View b = batches[ch.batch].v;
+  const int* __restrict__ order = batches[ch.batch].order;
+  const int* __restrict__ term_lo = batches[ch.batch].term_lo;
+  const int* __restrict__ term_nbuf = batches[ch.batch].term_nbuf;
+  const int* of = dc.ofp_data + dc.ofp_off[ch.ofp];
+  const int nob = of[0], G = of[1];
+  const int* oblk = of + OFP_HDR;   // nob x (block index, dim, local column start, global column base)
+  const int nb = ch.pose_nb, T = ch.term_count, ld = dm.ld;
+  const int pb = nb > 0 ? b_pose_first_block(b) + ch.pose_lo : 0;
+  double* rows = smem;
+  int* ip = (int*)(rows + (size_t)dm.maxT * D * ld);
+  int* beta0 = ip; ip += dm.maxT;
+  int* rlo = ip; ip += dm.maxNb + 1;
+  int* rhi = ip; ip += dm.maxNb + 1;
+  int* band_slot = ip; ip += dm.maxNb * 6;
+  int* hcol = ip; ip += dm.maxNb + 1;
+  int* arrow_slot = ip; ip += dm.maxNob * dm.maxNb + 1;
+  int* oo_slot = ip; ip += dm.maxNob * dm.maxNob + 1;
+  int* oh = ip; ip += dm.maxNob + 1;
+  int* ocolblk = ip; ip += dm.maxG + 1;
+  __shared__ double red[4];
+  const bool build = dc.build != 0;
+  if (build) {
+    for (int i = tid; i < T * D * ld; i += 256) rows[i] = 0.0;
+    for (int i = tid; i <= nb; i += 256) { rlo[i] = 0x7fffffff; rhi[i] = 0; }
+    for (int i = tid; i < nb * 6; i += 256) {
+      int bj = i / 6, bi = bj - (i % 6);
+      band_slot[i] = bi >= 0 ? slot_lookup(dc, pb + bi, pb + bj) : -1;
+    }
+    for (int i = tid; i < nb; i += 256) hcol[i] = dc.col_h[pb + i];
+    for (int i = tid; i < nob * nb; i += 256) {
+      int ob = oblk[4 * (i / nb)], pk = pb + (i % nb);
+      arrow_slot[i] = ob < pk ? slot_lookup(dc, ob, pk) : slot_lookup(dc, pk, ob);
+    }
+    for (int i = tid; i < nob * nob; i += 256) {
+      int b1 = oblk[4 * (i / nob)], b2 = oblk[4 * (i % nob)];
+      oo_slot[i] = b1 <= b2 ? slot_lookup(dc, b1, b2) : -1;
+    }
+    for (int i = tid; i < nob; i += 256) {
+      oh[i] = dc.col_h[oblk[4 * i]];
+      for (int c = 0; c < oblk[4 * i + 1]; ++c) ocolblk[oblk[4 * i + 2] + c] = i;
+    }
+    __syncthreads();
+  }
+  // ---- phase 1: one term per thread
+  double Jacc = 0.0;
+  if (tid < T) {
+    const int u = order[ch.term_first + tid];
+    double e[D];
+    TermOut out;
+    int st = 0;
+    double* Jrow = rows + (size_t)tid * D * ld;
+    int b0 = StreamTraits<View>::eval(b, dc.x, u, dc.useM != 0, build, of, ch.pose_lo, nb, term_lo[u], term_nbuf[u], Jrow, ld, e, out, &st);
+    if (b0 >= 0) {
+      Jacc = out.w * out.chi2;
+      dc.chi2[b.term_base_global + u] = out.chi2;
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        if (dc.e) dc.e[b.row_base + D * u + r] = -e[r];
+        if (build) Jrow[r * ld + 36 + G] = e[r];
+      }
+      if (build) {
+        beta0[tid] = b0;
+        if (nb > 0) { atomicMin(&rlo[b0], tid); atomicMax(&rhi[b0], tid + 1); }
+      }
+    } else {
+      atomicOr(dc.status, st);
+      if (build) beta0[tid] = -1000;   // covers nothing
+    }
+  }
+  Jacc = wave_sum(Jacc);
+  if ((tid & 63) == 0) red[tid >> 6] = Jacc;
+  __syncthreads();
+  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (!build) return;
+  // Terms are time sorted and share one time offset, so beta0 is non-decreasing over the chunk and the terms of
+  // segment s are exactly the run [rlo[s], rhi[s]) (a failed term inside a run has an all-zero row).  A violation
+  // would silently drop products, so it is checked and reported.
+  if (tid > 0 && tid < T && beta0[tid] >= 0 && beta0[tid - 1] >= 0 && beta0[tid] < beta0[tid - 1]) atomicOr(dc.status, STATUS_INTERNAL);
+  if (dc.build == 3) return;
+  const int ecol = 36 + G;
+  (void)ecol;
+  const int rstride = D * ld;
+  // ---- phase 2 (i): coefficient band.  idx -> (scalar column of block bj, row rho down the 6 blocks ending at the diagonal)
+  for (int idx = tid; idx < nb * 216; idx += 256) {
+    const int col = idx / 36, rho = idx - 36 * col;
+    const int bj = col / 6, cb = col - 6 * bj;
+    const int d = 5 - rho / 6, ra = rho % 6;
+    const int bi = bj - d;
+    if (bi < 0 || (d == 0 && ra > cb)) continue;
+    const int slot = band_slot[bj * 6 + d];
+    if (slot < 0) continue;
+    double acc = 0.0;
+    for (int sg = max(0, bj - 5); sg <= bi; ++sg) {
+      const int kb = rhi[sg], ka = min(rlo[sg], kb);
+      const double* p1 = rows + (size_t)ka * rstride + (bi - sg) * 6 + ra;
+      const double* p2 = rows + (size_t)ka * rstride + (bj - sg) * 6 + cb;
+#pragma unroll 2
+      for (int k = ka; k < kb; ++k, p1 += rstride, p2 += rstride) {
+#pragma unroll
+        for (int r = 0; r < D; ++r) acc += p1[r * ld] * p2[r * ld];
+      }
+    }
+    if (acc != 0.0 && dc.build == 1) atomic_add_f64(dc.Cx + slot + cb * hcol[bj] + (cb * (cb + 1)) / 2 + ra, acc);
+  }
+  // ---- phase 2 (ii): coefficient x other columns (and the coefficient part of rhs: other column G = residual)
+  const int npc = 6 * nb;
+  for (int idx = tid; idx < (G + 1) * npc; idx += 256) {
+    const int g = idx / npc, pc = idx - g * npc;
+    const int bi = pc / 6, ra = pc - 6 * bi;
+    double acc = 0.0;
+    for (int sg = max(0, bi - 5); sg <= bi; ++sg) {
+      const int kb = rhi[sg], ka = min(rlo[sg], kb);
+      const double* p1 = rows + (size_t)ka * rstride + (bi - sg) * 6 + ra;
+      const double* p2 = rows + (size_t)ka * rstride + 36 + g;
+#pragma unroll 2
+      for (int k = ka; k < kb; ++k, p1 += rstride, p2 += rstride) {
+#pragma unroll
+        for (int r = 0; r < D; ++r) acc += p1[r * ld] * p2[r * ld];
+      }
+    }
+    if (acc == 0.0 || dc.build != 1) continue;
+    if (g == G) { atomic_add_f64(dc.rhs + b_pose_first_col(b) + 6 * (ch.pose_lo + bi) + ra, -acc); continue; }
+    const int o = ocolblk[g], sc = g - oblk[4 * o + 2];
+    const int slot = arrow_slot[o * nb + bi];
+    if (slot < 0) continue;
+    if (oblk[4 * o] < pb + bi) atomic_add_f64(dc.Cx + slot + ra * hcol[bi] + (ra * (ra + 1)) / 2 + sc, acc);   // column = coefficient
+    else atomic_add_f64(dc.Cx + slot + sc * oh[o] + (sc * (sc + 1)) / 2 + ra, acc);                          // column = other
+  }
+  // ---- phase 2 (iii): other x other (upper triangle) and the other part of rhs
+  const int G1 = G + 1;
+  for (int idx = tid; idx < G1 * G1; idx += 256) {
+    const int g2 = idx / G1, g1 = idx - g2 * G1;
+    if (g1 > g2 || g1 == G) continue;
+    double acc = 0.0;
+    for (int k = 0; k < T; ++k) {
+      const double* row = rows + (size_t)k * rstride;
+#pragma unroll
+      for (int r = 0; r < D; ++r) acc += row[r * ld + 36 + g1] * row[r * ld + 36 + g2];
+    }
+    if (acc == 0.0 || dc.build != 1) continue;
+    const int o1 = ocolblk[g1], s1 = g1 - oblk[4 * o1 + 2];
+    if (g2 == G) { atomic_add_f64(dc.rhs + oblk[4 * o1 + 3] + s1, -acc); continue; }
+    const int o2 = ocolblk[g2], s2 = g2 - oblk[4 * o2 + 2];
+    if (o1 == o2) {
+      int slot = oo_slot[o1 * nob + o1];
+      if (slot >= 0) atomic_add_f64(dc.Cx + slot + s2 * oh[o1] + (s2 * (s2 + 1)) / 2 + s1, acc);
+    } else if (oblk[4 * o1] < oblk[4 * o2]) {
+      int slot = oo_slot[o1 * nob + o2];
+      if (slot >= 0) atomic_add_f64(dc.Cx + slot + s2 * oh[o2] + (s2 * (s2 + 1)) / 2 + s1, acc);
+    } else {
+      int slot = oo_slot[o2 * nob + o1];
+      if (slot >= 0) atomic_add_f64(dc.Cx + slot + s1 * oh[o1] + (s1 * (s1 + 1)) / 2 + s2, acc);
+    }
+  }
+}
+
+template <class View>
+__global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, DevCommon dc, const GroupRec* __restrict__ groups,
+                                              int jpart_base) {
   extern __shared__ double tile[];
   constexpr int D = TermTraits<View>::D;
   const int lane = threadIdx.x;
   const GroupRec gr = groups[blockIdx.x];
+  const View b = views[gr.batch];
   FpView f = fp_view(dc, gr.fp);
   const int C = f.C;
   const int ld = (C + 1) | 1;
@@ -312,7 +541,8 @@ struct MotionView {
   int row;               // row of this term in e
   int term;              // global term index
 };
-__global__ __launch_bounds__(256) void k_motion(MotionView m, DevCommon dc, int jpart_base) {
+__global__ __launch_bounds__(256) void k_motion(const MotionView* __restrict__ views, DevCommon dc, int jpart_base) {
+  const MotionView m = views[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int D = m.D, S = m.S;
   double part = 0.0;
@@ -351,16 +581,16 @@ __global__ __launch_bounds__(256) void k_motion(MotionView m, DevCommon dc, int 
   __syncthreads();
   if (threadIdx.x == 0) {
     double s = red[0] + red[1] + red[2] + red[3];
-    dc.Jpart[jpart_base + blockIdx.x] = s;
+    dc.Jpart[jpart_base + blockIdx.y * gridDim.x + blockIdx.x] = s;
   }
   if (i == 0) { if (dc.e) dc.e[m.row] = 0.0; }
 }
 // chi^2 of a motion term = sum of its partials (raw squared error, BSplineMotionError.hpp:76)
-__global__ void k_motion_chi2(const double* Jpart, int base, int n, double* chi2, int term) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ void k_motion_chi2(const MotionView* __restrict__ views, const double* Jpart, int base, int n, double* chi2) {
+  if (threadIdx.x == 0) {
     double s = 0;
-    for (int i = 0; i < n; ++i) s += Jpart[base + i];
-    chi2[term] = s;
+    for (int i = 0; i < n; ++i) s += Jpart[base + blockIdx.x * n + i];
+    chi2[views[blockIdx.x].term] = s;
   }
 }
 
@@ -368,14 +598,17 @@ __global__ void k_motion_chi2(const double* Jpart, int base, int n, double* chi2
 __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ part, int n, double* out) {
   __shared__ double red[256];
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  // block b sums the slice [b * per, (b+1) * per) in a fixed order -> out[b]; a second launch with one block finishes
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) s += part[i];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = red[0];
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 // Optimizer2::applyStateUpdate (Optimizer2.cpp:292-309) + every DesignVariable::updateImplementation
@@ -425,12 +658,27 @@ template <class T> struct DevBuf {
   ~DevBuf() { release(); }
 };
 
+// Per-batch device arrays (the SoA term records).
 struct DevBatch {
   DevBuf<double> t, y, p, sinv, meas, range, Qband;
-  DevBuf<int> obs_first, obs_q_off, obs_t_off, term_q_off, term_t_off, term_obs, slot;
+  DevBuf<int> obs_first, obs_q_off, obs_t_off, term_q_off, term_t_off, term_obs, slot, order, term_lo, term_nbuf;
+};
+
+// One kernel launch per term family: the batches (sensor streams) of a family share the launch through a device array
+// of their views; work items (groups / chunks) carry the index of their batch.
+enum { LAUNCH_REPROJ = 0, LAUNCH_STATIC = 1, LAUNCH_IMU = 2, LAUNCH_LIDAR = 3, LAUNCH_MOTION = 4, N_LAUNCH = 5 };
+struct LaunchUnit {
+  int n_batches = 0, n_terms = 0, n_items = 0, jpart_base = 0, n_jpart = 0, lds_bytes = 0;
+  double flops_dense = 0, flops_live = 0, rec_bytes = 0;
+  StreamDims dims{0, 0, 0, 0, 0};
+  int motion_blocks = 0;
   DevBuf<GroupRec> groups;
-  int n_groups = 0, jpart_base = 0, n_jpart = 0, lds_bytes = 0;
-  ReprojBatchView rv; LidarBatchView lv; ImuBatchView iv; StaticReprojBatchView sv; MotionView mv;
+  DevBuf<ChunkRec> chunks;
+  DevBuf<ReprojBatchView> rviews;
+  DevBuf<StaticReprojBatchView> sviews;
+  DevBuf<StreamBatch<ImuBatchView>> iviews;
+  DevBuf<StreamBatch<LidarBatchView>> lviews;
+  DevBuf<MotionView> mviews;
 };
 
 }  // namespace mc
@@ -441,10 +689,11 @@ struct mc_context {
   Problem P;
   std::string err;
   int device = 0;
-  DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, J, dx;
-  DevBuf<int> fp_data, fp_off, col_h, status;
+  DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, Jpart2, J, dx;
+  DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0;
   DevBuf<UpdRec> upd;
   std::vector<std::unique_ptr<DevBatch>> db;
+  LaunchUnit lu[N_LAUNCH];
   int n_jpart = 0;
   bool have_prev = false;
 
@@ -455,6 +704,41 @@ struct mc_context {
 
 static thread_local std::string g_create_error;
 
+static int launchOf(int kind) {
+  switch (kind) {
+    case KIND_REPROJ: return LAUNCH_REPROJ;
+    case KIND_STATIC_REPROJ: return LAUNCH_STATIC;
+    case KIND_ACCEL: case KIND_GYRO: return LAUNCH_IMU;
+    case KIND_LIDAR: return LAUNCH_LIDAR;
+    default: return LAUNCH_MOTION;
+  }
+}
+
+void batchCounts(const Problem& P, const Batch& b, double& fd, double& fl, double& rec) {
+  // buildSystem flops with every structurally present block (dense: what the reference computes, padded
+  // zero blocks included), with the live blocks only, and the compulsory record bytes
+  static const double fjac[6] = {3500.0, 3500.0, 6000.0, 3000.0, 3000.0, 0.0};
+  static const double recb[6] = {72.0, 72.0, 52.0, 52.0, 64.0, 0.0};
+  fd = b.flops_dense; fl = b.flops_live;
+  for (const GroupRec& g : b.groups) {
+    double s1 = 0, s2 = 0, l1 = 0, l2 = 0;
+    for (int blk : P.fp_pattern[g.fp]) { double d = P.block_dim[blk]; s1 += d; s2 += d * d; }
+    for (auto& w : P.fp_written[g.fp]) {
+      int n = w[2];
+      if (w[0] == 0 && b.kind == KIND_REPROJ) n = std::min(n, 6);  // live support
+      for (int k = 0; k < n; ++k) { double d = P.block_dim[w[1] + k]; l1 += d; l2 += d * d; }
+    }
+    double D = b.dim;
+    fd += g.term_count * (2.0 * D * 0.5 * (s1 * s1 + s2) + 2.0 * D * s1 + fjac[b.kind]);
+    fl += g.term_count * (2.0 * D * 0.5 * (l1 * l1 + l2) + 2.0 * D * l1 + fjac[b.kind]);
+  }
+  if (b.kind == KIND_MOTION) {
+    const SplineRec& sp = P.splines[b.spline];
+    fd = fl = 2.0 * sp.n_coeff * (2 * sp.order - 1) * sp.dim * sp.dim;
+  }
+  rec = recb[b.kind] * b.n_terms;
+}
+
 void mc_context::uploadStructure() {
   HIP_CHECK(hipSetDevice(device));
   x.upload(P.x);
@@ -464,34 +748,61 @@ void mc_context::uploadStructure() {
   fp_data.upload(P.fp_data);
   fp_off.upload(P.fp_off);
   col_h.upload(P.col_h);
+  ofp_data.upload(P.ofp_data); ofp_off.upload(P.ofp_off);
+  pat_colptr.upload(P.pat_colptr); pat_rows.upload(P.pat_rows); pat_roff.upload(P.pat_roff); pat_cp0.upload(P.pat_cp0);
   status.alloc(1);
   Cx.alloc(P.nnz); rhs.alloc(P.j_cols); e.alloc(P.j_rows); chi2.alloc(P.n_terms); J.alloc(1); dx.alloc(P.j_cols);
   std::vector<UpdRec> ur;
   for (int dv : P.update_dvs) { const DvRec& d = P.dvs[dv]; ur.push_back(UpdRec{d.kind, d.dim, d.off, d.col, d.scaling}); }
   upd.upload(ur);
-  n_jpart = 0;
   db.clear();
+  std::vector<GroupRec> groups[N_LAUNCH];
+  std::vector<ChunkRec> chunks[N_LAUNCH];
+  std::vector<ReprojBatchView> rviews;
+  std::vector<StaticReprojBatchView> sviews;
+  std::vector<StreamBatch<ImuBatchView>> iviews;
+  std::vector<StreamBatch<LidarBatchView>> lviews;
+  std::vector<MotionView> mviews;
+  for (int l = 0; l < N_LAUNCH; ++l) lu[l] = LaunchUnit();
   int term_base = 0;
   for (Batch& b : P.batches) {
     std::unique_ptr<DevBatch> d(new DevBatch());
     auto offs = [&](const std::vector<int>& ids) { std::vector<int> o(ids.size()); for (size_t i = 0; i < ids.size(); ++i) o[i] = P.dvs[ids[i]].off; return o; };
-    d->jpart_base = n_jpart;
-    if (b.kind != KIND_MOTION) {
-      std::vector<GroupRec> mine;
-      for (const GroupRec& g : b.my_groups) if (g.term_count > 0) mine.push_back(g);
-      d->groups.upload(mine);
-      d->n_groups = (int)mine.size();
-      d->n_jpart = d->n_groups;
+    LaunchUnit& L = lu[launchOf(b.kind)];
+    const int li = launchOf(b.kind);
+    const int view_index = L.n_batches++;
+    L.n_terms += b.n_terms;
+    {
+      double fd, fl, rec;
+      batchCounts(P, b, fd, fl, rec);
+      const double share = 1.0 / P.world;   // this rank's part
+      L.flops_dense += fd * share; L.flops_live += fl * share; L.rec_bytes += rec * share;
+    }
+    const bool stream = b.kind == KIND_LIDAR || b.kind == KIND_ACCEL || b.kind == KIND_GYRO;
+    if (stream) {
+      for (ChunkRec c : b.my_chunks) { c.batch = view_index; chunks[li].push_back(c); }
+      d->order.upload(b.order); d->term_lo.upload(b.term_lo); d->term_nbuf.upload(b.term_nbuf);
+      StreamDims& dm = L.dims;
+      dm.maxT = std::max(dm.maxT, b.max_terms); dm.maxNb = std::max(dm.maxNb, b.max_nb);
+      dm.maxNob = std::max(dm.maxNob, b.max_nob); dm.maxG = std::max(dm.maxG, b.max_g);
+    } else if (b.kind != KIND_MOTION) {
       int maxR = 0, maxC = 0;
-      for (const GroupRec& g : mine) { maxR = std::max(maxR, g.term_count * b.dim); maxC = std::max(maxC, P.fp_data[P.fp_off[g.fp] + 1]); }
-      d->lds_bytes = maxR * ((maxC + 1) | 1) * (int)sizeof(double);
-      if (b.kind != KIND_REPROJ && d->lds_bytes > 64 * 1024) throw std::runtime_error("group tile exceeds the LDS budget");
+      for (GroupRec g : b.my_groups) {
+        if (g.term_count == 0) continue;
+        g.batch = view_index;
+        groups[li].push_back(g);
+        maxR = std::max(maxR, g.term_count * b.dim); maxC = std::max(maxC, P.fp_data[P.fp_off[g.fp] + 1]);
+      }
+      if (b.kind == KIND_STATIC_REPROJ) {
+        L.lds_bytes = std::max(L.lds_bytes, maxR * ((maxC + 1) | 1) * (int)sizeof(double));
+        if (L.lds_bytes > 64 * 1024) throw std::runtime_error("group tile exceeds the LDS budget");
+      }
     }
     d->sinv.upload(b.sinv);
     if (b.kind == KIND_REPROJ) {
       d->t.upload(b.t); d->y.upload(b.y); d->p.upload(b.p);
       d->obs_first.upload(b.obs_first); d->obs_q_off.upload(offs(b.obs_dv_q)); d->obs_t_off.upload(offs(b.obs_dv_t));
-      ReprojBatchView& v = d->rv;
+      ReprojBatchView v;
       v.cam = P.cameraView(b.cam);
       v.sp = P.splineView(b.spline, knots.p, basis.p);
       v.q_cb = P.dvRef(b.dv[0]); v.t_cb = P.dvRef(b.dv[1]); v.toff = P.dvRef(b.dv[2]);
@@ -501,19 +812,24 @@ void mc_context::uploadStructure() {
       v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
       v.row_base = b.row_base; v.term_base_global = term_base;
+      rviews.push_back(v);
     } else if (b.kind == KIND_LIDAR) {
       d->t.upload(b.t); d->p.upload(b.p); d->range.upload(b.range);
       d->term_q_off.upload(offs(b.term_dv_q)); d->term_t_off.upload(offs(b.term_dv_t));
-      LidarBatchView& v = d->lv;
+      StreamBatch<LidarBatchView> sb;
+      LidarBatchView& v = sb.v;
       v.sp = P.splineView(b.spline, knots.p, basis.p);
       v.q_lb = P.dvRef(b.dv[0]); v.t_lb = P.dvRef(b.dv[1]); v.toff = P.dvRef(b.dv[2]);
       v.coef_scale = 1.0; v.qpw_scale = 1.0; v.tpw_scale = 1.0;
       if (!b.term_dv_q.empty()) { v.qpw_scale = P.dvs[b.term_dv_q[0]].scaling; v.tpw_scale = P.dvs[b.term_dv_t[0]].scaling; }
       v.t = d->t.p; v.dir = d->p.p; v.range = d->range.p; v.sinv = d->sinv.p; v.qpw_off = d->term_q_off.p; v.tpw_off = d->term_t_off.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
+      sb.order = d->order.p; sb.term_lo = d->term_lo.p; sb.term_nbuf = d->term_nbuf.p;
+      lviews.push_back(sb);
     } else if (b.kind == KIND_ACCEL || b.kind == KIND_GYRO) {
       d->t.upload(b.t); d->meas.upload(b.meas);
-      ImuBatchView& v = d->iv;
+      StreamBatch<ImuBatchView> sb;
+      ImuBatchView& v = sb.v;
       v.pose = P.splineView(b.spline, knots.p, basis.p);
       v.bias = P.splineView(b.bias_spline, knots.p, basis.p);
       v.bias_dv = P.dvRef(b.dv[0]); v.g = P.dvRef(b.dv[1]); v.q_ib = P.dvRef(b.dv[2]); v.r_b = P.dvRef(b.dv[3]);
@@ -522,14 +838,17 @@ void mc_context::uploadStructure() {
       v.t = d->t.p; v.meas = d->meas.p; v.sinv = d->sinv.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.is_accel = b.kind == KIND_ACCEL ? 1 : 0;
       v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
+      sb.order = d->order.p; sb.term_lo = d->term_lo.p; sb.term_nbuf = d->term_nbuf.p;
+      iviews.push_back(sb);
     } else if (b.kind == KIND_STATIC_REPROJ) {
       d->y.upload(b.y); d->p.upload(b.p);
       d->obs_first.upload(b.obs_first); d->obs_q_off.upload(offs(b.obs_dv_q)); d->obs_t_off.upload(offs(b.obs_dv_t));
       d->term_obs.upload(b.term_obs);
-      StaticReprojBatchView& v = d->sv;
+      StaticReprojBatchView v;
       v.cam = P.cameraView(b.cam);
       v.n_chain = (int)b.chain_q.size();
       for (int j = 0; j < v.n_chain; ++j) { v.chain_q[j] = P.dvRef(b.chain_q[j]); v.chain_t[j] = P.dvRef(b.chain_t[j]); }
+      for (int j = v.n_chain; j < F2_MAX_CHAIN; ++j) { v.chain_q[j] = P.dvRef(-1); v.chain_t[j] = P.dvRef(-1); }
       v.qtc_scale = 1.0; v.ttc_scale = 1.0;
       if (!b.obs_dv_q.empty()) { v.qtc_scale = P.dvs[b.obs_dv_q[0]].scaling; v.ttc_scale = P.dvs[b.obs_dv_t[0]].scaling; }
       v.proj_scale = P.dvs[P.cams[b.cam].dv_proj].scaling;
@@ -538,6 +857,7 @@ void mc_context::uploadStructure() {
       v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
       v.row_base = b.row_base; v.term_base_global = term_base;
+      sviews.push_back(v);
     } else {  // KIND_MOTION: handled by rank 0 only (one whole-spline term)
       const SplineRec& s = P.splines[b.spline];
       d->Qband.upload(b.Qband);
@@ -551,24 +871,64 @@ void mc_context::uploadStructure() {
             slot[(size_t)i * s.order + dd] = P.Cp[P.block_col[b0 + i]] + P.col_roff[b0 + i][k];
           }
       d->slot.upload(slot);
-      MotionView& v = d->mv;
+      MotionView v;
       v.Qband = d->Qband.p; v.slot = d->slot.p; v.n_coeff = s.n_coeff; v.S = s.order; v.D = s.dim;
       v.param_off = s.param_off; v.first_block = b0; v.first_col = b0 >= 0 ? P.dvs[s.first_dv].col : -1;
       v.row = b.row_base; v.term = term_base;
-      d->n_groups = P.rank == 0 ? (s.n_coeff + 255) / 256 : 0;
-      d->n_jpart = d->n_groups;
+      mviews.push_back(v);
+      L.motion_blocks = std::max(L.motion_blocks, (s.n_coeff + 255) / 256);
     }
-    n_jpart += d->n_jpart;
     term_base += b.n_terms;
     db.push_back(std::move(d));
   }
+  // launch list
+  n_jpart = 0;
+  for (int l = 0; l < N_LAUNCH; ++l) {
+    LaunchUnit& L = lu[l];
+    L.jpart_base = n_jpart;
+    if (l == LAUNCH_MOTION) {
+      L.n_items = P.rank == 0 ? (int)mviews.size() : 0;
+      L.n_jpart = L.n_items * L.motion_blocks;
+      if (P.rank != 0) { L.flops_dense = L.flops_live = 0; }
+    } else if (l == LAUNCH_IMU || l == LAUNCH_LIDAR) {
+      L.chunks.upload(chunks[l]);
+      L.n_items = (int)chunks[l].size();
+      L.n_jpart = L.n_items;
+      StreamDims& dm = L.dims;
+      dm.ld = (36 + dm.maxG + 1) | 1;
+      const int dim = l == LAUNCH_IMU ? 3 : 1;
+      size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + 6 * dm.maxNb + (dm.maxNb + 1) + ((size_t)dm.maxNob * dm.maxNb + 1) +
+                    ((size_t)dm.maxNob * dm.maxNob + 1) + (dm.maxNob + 1) + (dm.maxG + 1);
+      L.lds_bytes = (int)((size_t)dm.maxT * dim * dm.ld * sizeof(double) + ints * sizeof(int) + 16);
+      if (L.lds_bytes > 150 * 1024) throw std::runtime_error("chunk tile exceeds the LDS budget");
+      if (L.lds_bytes > 64 * 1024) {
+        if (l == LAUNCH_LIDAR)
+          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<LidarBatchView>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+        else
+          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<ImuBatchView>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+      }
+    } else {
+      L.groups.upload(groups[l]);
+      L.n_items = (int)groups[l].size();
+      L.n_jpart = L.n_items;
+    }
+    n_jpart += L.n_jpart;
+  }
+  lu[LAUNCH_REPROJ].rviews.upload(rviews);
+  lu[LAUNCH_STATIC].sviews.upload(sviews);
+  lu[LAUNCH_IMU].iviews.upload(iviews);
+  lu[LAUNCH_LIDAR].lviews.upload(lviews);
+  lu[LAUNCH_MOTION].mviews.upload(mviews);
   Jpart.alloc(std::max(1, n_jpart));
+  Jpart2.alloc(256);
 }
 
 void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
                            std::vector<hipEvent_t>* ev) {
   DevCommon dc;
   dc.x = x.p; dc.fp_data = fp_data.p; dc.fp_off = fp_off.p; dc.col_h = col_h.p;
+  dc.ofp_data = ofp_data.p; dc.ofp_off = ofp_off.p;
+  dc.pat_colptr = pat_colptr.p; dc.pat_rows = pat_rows.p; dc.pat_roff = pat_roff.p; dc.pat_cp0 = pat_cp0.p;
   dc.Cx = dCx; dc.rhs = dRhs; dc.e = dE; dc.chi2 = chi2.p; dc.Jpart = Jpart.p; dc.status = status.p;
   dc.useM = useM; dc.build = build;
   if (build) {
@@ -576,35 +936,40 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     HIP_CHECK(hipMemsetAsync(dRhs, 0, sizeof(double) * P.j_cols, st));
   }
   if (dE && P.world > 1) HIP_CHECK(hipMemsetAsync(dE, 0, sizeof(double) * P.j_rows, st));
-  for (size_t i = 0; i < db.size(); ++i) {
-    DevBatch& d = *db[i];
-    const Batch& b = P.batches[i];
-    if (ev) HIP_CHECK(hipEventRecord((*ev)[i], st));
-    if (d.n_groups == 0) continue;
-    switch (b.kind) {
-      case KIND_REPROJ:
-        hipLaunchKernelGGL(k_reproj, dim3(d.n_groups), dim3(64), 0, st, d.rv, dc, d.groups.p, d.jpart_base);
+  for (int l = 0; l < N_LAUNCH; ++l) {
+    LaunchUnit& L = lu[l];
+    if (ev) HIP_CHECK(hipEventRecord((*ev)[l], st));
+    if (L.n_items == 0) continue;
+    switch (l) {
+      case LAUNCH_REPROJ:
+        hipLaunchKernelGGL(k_reproj, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.jpart_base);
         break;
-      case KIND_LIDAR:
-        hipLaunchKernelGGL(k_group<LidarBatchView>, dim3(d.n_groups), dim3(64), d.lds_bytes, st, d.lv, dc, d.groups.p, d.jpart_base);
+      case LAUNCH_STATIC:
+        hipLaunchKernelGGL(k_group<StaticReprojBatchView>, dim3(L.n_items), dim3(64), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.jpart_base);
         break;
-      case KIND_ACCEL: case KIND_GYRO:
-        hipLaunchKernelGGL(k_group<ImuBatchView>, dim3(d.n_groups), dim3(64), d.lds_bytes, st, d.iv, dc, d.groups.p, d.jpart_base);
+      case LAUNCH_IMU:
+        hipLaunchKernelGGL(k_stream<ImuBatchView>, dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
-      case KIND_STATIC_REPROJ:
-        hipLaunchKernelGGL(k_group<StaticReprojBatchView>, dim3(d.n_groups), dim3(64), d.lds_bytes, st, d.sv, dc, d.groups.p, d.jpart_base);
+      case LAUNCH_LIDAR:
+        hipLaunchKernelGGL(k_stream<LidarBatchView>, dim3(L.n_items), dim3(256), L.lds_bytes, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
-      case KIND_MOTION:
-        hipLaunchKernelGGL(k_motion, dim3(d.n_groups), dim3(256), 0, st, d.mv, dc, d.jpart_base);
-        hipLaunchKernelGGL(k_motion_chi2, dim3(1), dim3(64), 0, st, Jpart.p, d.jpart_base, d.n_jpart, chi2.p, d.mv.term);
+      case LAUNCH_MOTION:
+        hipLaunchKernelGGL(k_motion, dim3(L.motion_blocks, L.n_items), dim3(256), 0, st, L.mviews.p, dc, L.jpart_base);
+        hipLaunchKernelGGL(k_motion_chi2, dim3(L.n_items), dim3(64), 0, st, L.mviews.p, Jpart.p, L.jpart_base, L.motion_blocks, chi2.p);
         break;
     }
     HIP_CHECK(hipGetLastError());
   }
-  if (ev) HIP_CHECK(hipEventRecord((*ev)[db.size()], st));
+  if (ev) HIP_CHECK(hipEventRecord((*ev)[N_LAUNCH], st));
   if (!build || dJ) {
     double* out = dJ ? dJ : J.p;
-    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, Jpart.p, n_jpart, out);
+    int nblk = std::min(256, std::max(1, n_jpart / 1024));
+    if (nblk > 1) {
+      hipLaunchKernelGGL(k_sum, dim3(nblk), dim3(256), 0, st, Jpart.p, n_jpart, Jpart2.p);
+      hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, Jpart2.p, nblk, out);
+    } else {
+      hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, Jpart.p, n_jpart, out);
+    }
     HIP_CHECK(hipGetLastError());
   }
 }
@@ -764,55 +1129,31 @@ int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double*
   return 0;
   MC_CATCH(ctx, -1)
 }
-int mc_num_batches(const mc_context* ctx) { return (int)ctx->P.batches.size(); }
-int mc_batch_info(const mc_context* ctx, int batch, int* kind, int* n_terms, int* n_groups) {
-  if (!ctx->P.finalized || batch < 0 || batch >= (int)ctx->P.batches.size()) return -1;
-  const Batch& b = ctx->P.batches[batch];
-  if (kind) *kind = b.kind;
-  if (n_terms) *n_terms = b.n_terms;
-  if (n_groups) *n_groups = ctx->db[batch]->n_groups;
+int mc_num_launches(const mc_context*) { return N_LAUNCH; }
+int mc_launch_info(const mc_context* ctx, int launch, int* n_batches, int* n_terms, int* n_workgroups) {
+  if (!ctx->P.finalized || launch < 0 || launch >= N_LAUNCH) return -1;
+  const LaunchUnit& L = ctx->lu[launch];
+  if (n_batches) *n_batches = L.n_batches;
+  if (n_terms) *n_terms = L.n_terms;
+  if (n_workgroups) *n_workgroups = launch == LAUNCH_MOTION ? L.n_items * L.motion_blocks : L.n_items;
   return 0;
 }
-// SURVEY.md 8(d) accounting for one batch: algorithmic flops of buildSystem with every structurally present
-// block counted (dense, what the reference computes, padded zero blocks included), the same with only the
-// blocks that can be non-zero (live), and the compulsory record bytes.
-int mc_batch_counts(const mc_context* ctx, int batch, double* flops_dense, double* flops_live, double* record_bytes) {
-  if (!ctx->P.finalized || batch < 0 || batch >= (int)ctx->P.batches.size()) return -1;
-  const Problem& P = ctx->P;
-  const Batch& b = P.batches[batch];
-  static const double fjac[6] = {3500.0, 3500.0, 6000.0, 3000.0, 3000.0, 0.0};
-  static const double rec[6] = {72.0, 72.0, 52.0, 52.0, 64.0, 0.0};
-  double fd = 0, fl = 0;
-  for (const GroupRec& g : b.groups) {
-    double s1 = 0, s2 = 0, l1 = 0, l2 = 0;
-    for (int blk : P.fp_pattern[g.fp]) { double d = P.block_dim[blk]; s1 += d; s2 += d * d; }
-    for (auto& w : P.fp_written[g.fp]) {
-      int n = w[2];
-      if (w[0] == 0 && (b.kind == KIND_REPROJ || b.kind == KIND_LIDAR)) n = std::min(n, 6);  // live support
-      for (int k = 0; k < n; ++k) { double d = P.block_dim[w[1] + k]; l1 += d; l2 += d * d; }
-    }
-    double D = b.dim;
-    fd += g.term_count * (2.0 * D * 0.5 * (s1 * s1 + s2) + 2.0 * D * s1 + fjac[b.kind]);
-    fl += g.term_count * (2.0 * D * 0.5 * (l1 * l1 + l2) + 2.0 * D * l1 + fjac[b.kind]);
-  }
-  if (b.kind == KIND_MOTION) {
-    const SplineRec& sp = P.splines[b.spline];
-    fd = fl = 2.0 * sp.n_coeff * (2 * sp.order - 1) * sp.dim * sp.dim;
-  }
-  if (flops_dense) *flops_dense = fd;
-  if (flops_live) *flops_live = fl;
-  if (record_bytes) *record_bytes = rec[b.kind] * b.n_terms;
+int mc_launch_counts(const mc_context* ctx, int launch, double* flops_dense, double* flops_live, double* record_bytes) {
+  if (!ctx->P.finalized || launch < 0 || launch >= N_LAUNCH) return -1;
+  const LaunchUnit& L = ctx->lu[launch];
+  if (flops_dense) *flops_dense = L.flops_dense;
+  if (flops_live) *flops_live = L.flops_live;
+  if (record_bytes) *record_bytes = L.rec_bytes;
   return 0;
 }
-int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float* ms_per_batch) {
+int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float* ms_per_launch) {
   MC_TRY MC_NEED_FINAL(ctx);
   HIP_CHECK(hipSetDevice(ctx->device));
-  size_t n = ctx->db.size();
-  std::vector<hipEvent_t> ev(n + 1);
+  std::vector<hipEvent_t> ev(N_LAUNCH + 1);
   for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
   ctx->launchAll(build, use_mestimator, ctx->Cx.p, ctx->rhs.p, build ? nullptr : ctx->J.p, nullptr, 0, &ev);
   HIP_CHECK(hipStreamSynchronize(0));
-  for (size_t i = 0; i < n; ++i) HIP_CHECK(hipEventElapsedTime(&ms_per_batch[i], ev[i], ev[i + 1]));
+  for (int i = 0; i < N_LAUNCH; ++i) HIP_CHECK(hipEventElapsedTime(&ms_per_launch[i], ev[i], ev[i + 1]));
   for (auto& e : ev) (void)hipEventDestroy(e);
   return 0;
   MC_CATCH(ctx, -1)
@@ -865,6 +1206,7 @@ int mc_device_status(mc_context* ctx) {
   if (s) HIP_CHECK(hipMemset(ctx->status.p, 0, sizeof(int)));
   if (s & STATUS_BUFFER_EXCEEDED) ctx->err = "Spline Coefficient Buffer Exceeded. Set larger buffer margins!";
   else if (s & STATUS_TIME_OUT_OF_SPLINE) ctx->err = "The time is out of range of the spline";
+  else if (s & STATUS_INTERNAL) ctx->err = "internal error: chunk terms are not ordered by spline segment";
   return s;
   MC_CATCH(ctx, -1)
 }

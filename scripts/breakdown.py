@@ -12,19 +12,12 @@ W = synth.make_world(cfg)
 meas = synth.synthesize(W, lambda: HipApi(0), noise=True)
 spec, H = synth.build_spec(W, synth.initial_state(W), meas)
 api = HipApi(0); spec.emit(api); api.finalize()
-info = api.batch_info()
-names = {0: "reproj", 1: "static", 2: "accel", 3: "gyro", 4: "lidar", 5: "motion"}
+info = api.launch_info()
 res = {}
 for mode in (0, 3, 2, 1):
     for _ in range(2): api.build_system_timed(True, mode)
-    ms = np.mean([api.build_system_timed(True, mode) for _ in range(5)], axis=0)
-    res[mode] = ms
-agg = {}
-for i, (kind, nt, ng) in enumerate(info):
-    a = agg.setdefault(names[kind], dict(n=0, terms=0, groups=0, ms={m: 0.0 for m in res}))
-    a["n"] += 1; a["terms"] += nt; a["groups"] += ng
-    for m in res: a["ms"][m] += float(res[m][i])
-for k, a in agg.items():
-    print("%-7s batches %3d terms %8d groups %7d (%.1f terms/group) | eval %.3f  jac %.3f  +gram %.3f  full %.3f ms" %
-          (k, a["n"], a["terms"], a["groups"], a["terms"] / max(1, a["groups"]), a["ms"][0], a["ms"][3], a["ms"][2], a["ms"][1]))
+    res[mode] = np.mean([api.build_system_timed(True, mode) for _ in range(5)], axis=0)
+for i, (name, nbatch, nt, nwg, fd, fl, rb) in enumerate(info):
+    print("%-22s batches %3d terms %8d workgroups %7d (%.1f terms/wg) | eval %.3f  jac %.3f  +gram %.3f  full %.3f ms" %
+          (name, nbatch, nt, nwg, nt / max(1, nwg), res[0][i], res[3][i], res[2][i], res[1][i]))
 print("total: " + "  ".join("mode%d %.3f" % (m, float(res[m].sum())) for m in res))

@@ -91,8 +91,9 @@ int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {
   Problem& P = ((Probe*)h)->P;
   *mine = *total = *my_terms = 0;
   for (const Batch& b : P.batches) {
-    *mine += (int)b.my_groups.size(); *total += (int)b.groups.size();
+    *mine += (int)b.my_groups.size() + (int)b.my_chunks.size(); *total += (int)b.groups.size() + (int)b.chunks.size();
     for (const GroupRec& g : b.my_groups) *my_terms += g.term_count;
+    for (const ChunkRec& c : b.my_chunks) *my_terms += c.term_count;
   }
   return 0;
 }
@@ -103,6 +104,7 @@ int probe_my_terms(void* h, int* flags) {
   for (const Batch& b : P.batches) {
     for (int k = 0; k < b.n_terms; ++k) flags[base + k] = (b.kind == KIND_MOTION && P.rank == 0) ? 1 : 0;
     for (const GroupRec& g : b.my_groups) for (int k = 0; k < g.term_count; ++k) flags[base + g.term_first + k] = 1;
+    for (const ChunkRec& c : b.my_chunks) for (int k = 0; k < c.term_count; ++k) flags[base + b.order[c.term_first + k]] = 1;
     base += b.n_terms;
   }
   return 0;
