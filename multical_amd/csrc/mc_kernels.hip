@@ -89,6 +89,7 @@ __device__ __forceinline__ int global_col(const FpView& f, int ca) {
 // per-corner work is a 2 x 19 "core" row pair; the wave reduces the 20 x 20 core Gram matrix (column 19 is
 // the weighted residual) and expands it to the 6 live coefficient blocks with the basis weights.
 enum { F1_LD = F1_CORE + 2 };  // 21: odd stride, conflict-free column reads
+template <bool BUILD>
 __global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
                                                const GroupRec* __restrict__ groups, int jpart_base) {
   __shared__ double rows[128 * F1_LD];
@@ -101,11 +102,7 @@ __global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict
   // the per-image quantities (spline sample, transformation chain prefix) are wave-uniform: computed once, parked in
   // LDS and read back by broadcast so they do not occupy ~190 vector registers per lane
   __shared__ F1Common cm;
-  {
-    F1Common tmp;
-    f1_common(b, dc.x, gr.aux, tmp);
-    if (lane == 0) cm = tmp;
-  }
+  f1_common(b, dc.x, gr.aux, cm);   // every lane stores the same values (single-wave workgroup)
   __syncthreads();
   if (!cm.ok) {
     if (lane == 0) { atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
@@ -137,24 +134,19 @@ __global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict
     const int k = base + lane;
     const int nk = min(64, gr.term_count - base);
     if (k < gr.term_count) {
-      double core[2 * F1_CORE], e[2];
+      double e[2];
       TermOut out;
       const int term = gr.term_first + k;
-      f1_term(b, dc.x, cm, term, dc.useM != 0, dc.build != 0, core, e, out);
+      double* row = rows + (2 * lane) * F1_LD;
+      const F1Common* cmp = &cm;
+      asm volatile("" : "+v"(cmp));   // keeps the per-image block in LDS (otherwise its loads are hoisted into ~100 VGPRs)
+      f1_term(b, dc.x, *cmp, term, dc.useM != 0, BUILD, row, F1_LD, e, out);
       Jacc += out.w * out.chi2;
       dc.chi2[b.term_base_global + term] = out.chi2;
       if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
-      if (dc.build) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          double* row = rows + (2 * lane + r) * F1_LD;
-#pragma unroll
-          for (int c = 0; c < F1_CORE; ++c) row[c] = core[r * F1_CORE + c];
-          row[F1_CORE] = e[r];
-        }
-      }
+      if (BUILD) { row[F1_CORE] = e[0]; row[F1_LD + F1_CORE] = e[1]; }
     }
-    if (dc.build) {
+    if (BUILD) {
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -169,7 +161,7 @@ __global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict
   }
   Jacc = wave_sum(Jacc);
   if (lane == 0) dc.Jpart[jpart_base + blockIdx.x] = Jacc;
-  if (!dc.build) return;
+  if (!BUILD) return;
   if (dc.build == 3) { if (macc[0] == 1.2345e-300) dc.rhs[0] = 1.0; return; }
 #pragma unroll
   for (int q = 0; q < 4; ++q) if (lane + 64 * q < 210) Msh[lane + 64 * q] = macc[q];
@@ -302,7 +294,7 @@ template <> struct StreamTraits<ImuBatchView> {
   }
 };
 
-template <class View>
+template <class View, bool BUILD>
 __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
                                                 const ChunkRec* __restrict__ chunks, StreamDims dm, int jpart_base) {
   extern __shared__ double smem[];
@@ -330,7 +322,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
   int* oh = ip; ip += dm.maxNob + 1;
   int* ocolblk = ip; ip += dm.maxG + 1;
   __shared__ double red[4];
-  const bool build = dc.build != 0;
+  constexpr bool build = BUILD;
   if (build) {
     for (int i = tid; i < T * D * ld; i += 256) rows[i] = 0.0;
     for (int i = tid; i <= nb; i += 256) { rlo[i] = 0x7fffffff; rhi[i] = 0; }
@@ -392,51 +384,74 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
   const int ecol = 36 + G;
   (void)ecol;
   const int rstride = D * ld;
-  // ---- phase 2 (i): coefficient band.  idx -> (scalar column of block bj, row rho down the 6 blocks ending at the diagonal)
-  for (int idx = tid; idx < nb * 216; idx += 256) {
-    const int col = idx / 36, rho = idx - 36 * col;
-    const int bj = col / 6, cb = col - 6 * bj;
+  // ---- phase 2 (i): coefficient band.  One thread per (block column bj, row rho of the 6 blocks ending at the
+  // diagonal): it accumulates the 6 entries of that row inside block column bj, so every J element it loads feeds
+  // 6 multiply-adds; for a fixed column the 36 threads of a block column write 36 consecutive values.
+  for (int idx = tid; idx < nb * 36; idx += 256) {
+    const int bj = idx / 36, rho = idx - 36 * bj;
     const int d = 5 - rho / 6, ra = rho % 6;
     const int bi = bj - d;
-    if (bi < 0 || (d == 0 && ra > cb)) continue;
+    if (bi < 0) continue;
     const int slot = band_slot[bj * 6 + d];
     if (slot < 0) continue;
-    double acc = 0.0;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int sg = max(0, bj - 5); sg <= bi; ++sg) {
       const int kb = rhi[sg], ka = min(rlo[sg], kb);
       const double* p1 = rows + (size_t)ka * rstride + (bi - sg) * 6 + ra;
-      const double* p2 = rows + (size_t)ka * rstride + (bj - sg) * 6 + cb;
-#pragma unroll 2
+      const double* p2 = rows + (size_t)ka * rstride + (bj - sg) * 6;
       for (int k = ka; k < kb; ++k, p1 += rstride, p2 += rstride) {
 #pragma unroll
-        for (int r = 0; r < D; ++r) acc += p1[r * ld] * p2[r * ld];
+        for (int r = 0; r < D; ++r) {
+          const double xv = p1[r * ld];
+          const double2* q = reinterpret_cast<const double2*>(p2 + r * ld);   // 16-byte aligned: ld and 6 (bj - sg) are even
+          const double2 y01 = q[0], y23 = q[1], y45 = q[2];
+          acc[0] += xv * y01.x; acc[1] += xv * y01.y; acc[2] += xv * y23.x;
+          acc[3] += xv * y23.y; acc[4] += xv * y45.x; acc[5] += xv * y45.y;
+        }
       }
     }
-    if (acc != 0.0 && dc.build == 1) atomic_add_f64(dc.Cx + slot + cb * hcol[bj] + (cb * (cb + 1)) / 2 + ra, acc);
+    if (dc.build != 1) { if (acc[0] + acc[5] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    const int h = hcol[bj];
+#pragma unroll
+    for (int cb = 0; cb < 6; ++cb)
+      if (acc[cb] != 0.0 && !(d == 0 && ra > cb)) atomic_add_f64(dc.Cx + slot + cb * h + (cb * (cb + 1)) / 2 + ra, acc[cb]);
   }
-  // ---- phase 2 (ii): coefficient x other columns (and the coefficient part of rhs: other column G = residual)
-  const int npc = 6 * nb;
-  for (int idx = tid; idx < (G + 1) * npc; idx += 256) {
-    const int g = idx / npc, pc = idx - g * npc;
+  // ---- phase 2 (ii): coefficient x other columns (and the coefficient part of rhs: other column G = residual).
+  // One thread per (coefficient column, tile of GT other columns).
+  constexpr int GT = 7;
+  const int npc = 6 * nb, ngt = (G + 1 + GT - 1) / GT;
+  for (int idx = tid; idx < ngt * npc; idx += 256) {
+    const int gt = idx / npc, pc = idx - gt * npc;
     const int bi = pc / 6, ra = pc - 6 * bi;
-    double acc = 0.0;
+    const int g0 = gt * GT;
+    double acc[GT];
+#pragma unroll
+    for (int j = 0; j < GT; ++j) acc[j] = 0.0;
     for (int sg = max(0, bi - 5); sg <= bi; ++sg) {
       const int kb = rhi[sg], ka = min(rlo[sg], kb);
       const double* p1 = rows + (size_t)ka * rstride + (bi - sg) * 6 + ra;
-      const double* p2 = rows + (size_t)ka * rstride + 36 + g;
-#pragma unroll 2
+      const double* p2 = rows + (size_t)ka * rstride + 36 + g0;
       for (int k = ka; k < kb; ++k, p1 += rstride, p2 += rstride) {
 #pragma unroll
-        for (int r = 0; r < D; ++r) acc += p1[r * ld] * p2[r * ld];
+        for (int r = 0; r < D; ++r) {
+          const double xv = p1[r * ld];
+#pragma unroll
+          for (int j = 0; j < GT; ++j) acc[j] += xv * p2[r * ld + j];   // columns past G read the zeroed padding of the row
+        }
       }
     }
-    if (acc == 0.0 || dc.build != 1) continue;
-    if (g == G) { atomic_add_f64(dc.rhs + b_pose_first_col(b) + 6 * (ch.pose_lo + bi) + ra, -acc); continue; }
-    const int o = ocolblk[g], sc = g - oblk[4 * o + 2];
-    const int slot = arrow_slot[o * nb + bi];
-    if (slot < 0) continue;
-    if (oblk[4 * o] < pb + bi) atomic_add_f64(dc.Cx + slot + ra * hcol[bi] + (ra * (ra + 1)) / 2 + sc, acc);   // column = coefficient
-    else atomic_add_f64(dc.Cx + slot + sc * oh[o] + (sc * (sc + 1)) / 2 + ra, acc);                          // column = other
+    if (dc.build != 1) { if (acc[0] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      const int g = g0 + j;
+      if (g > G || acc[j] == 0.0) continue;
+      if (g == G) { atomic_add_f64(dc.rhs + b_pose_first_col(b) + 6 * (ch.pose_lo + bi) + ra, -acc[j]); continue; }
+      const int o = ocolblk[g], sc = g - oblk[4 * o + 2];
+      const int slot = arrow_slot[o * nb + bi];
+      if (slot < 0) continue;
+      if (oblk[4 * o] < pb + bi) atomic_add_f64(dc.Cx + slot + ra * hcol[bi] + (ra * (ra + 1)) / 2 + sc, acc[j]);   // column = coefficient
+      else atomic_add_f64(dc.Cx + slot + sc * oh[o] + (sc * (sc + 1)) / 2 + ra, acc[j]);                          // column = other
+    }
   }
   // ---- phase 2 (iii): other x other (upper triangle) and the other part of rhs
   const int G1 = G + 1;
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
   }
 }
 
-template <class View>
+template <class View, bool BUILD>
 __global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, DevCommon dc, const GroupRec* __restrict__ groups,
                                               int jpart_base) {
   extern __shared__ double tile[];
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, De
   const int C = f.C;
   const int ld = (C + 1) | 1;
   const int R = gr.term_count * D;
-  if (dc.build) {
+  if (BUILD) {
     for (int i = lane; i < R * ld; i += 64) tile[i] = 0.0;
     __syncthreads();
   }
@@ -489,14 +504,14 @@ __global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, De
     TermOut out;
     int st = 0;
     double* Jrow = tile + (size_t)(lane * D) * ld;
-    bool ok = TermTraits<View>::eval(b, dc.x, term, dc.useM != 0, dc.build != 0, f, Jrow, ld, e, out, &st);
+    bool ok = TermTraits<View>::eval(b, dc.x, term, dc.useM != 0, BUILD, f, Jrow, ld, e, out, &st);
     if (ok) {
       Jacc = out.w * out.chi2;
       dc.chi2[b.term_base_global + term] = out.chi2;
 #pragma unroll
       for (int r = 0; r < D; ++r) {
         if (dc.e) dc.e[b.row_base + D * term + r] = -e[r];
-        if (dc.build) Jrow[r * ld + C] = e[r];
+        if (BUILD) Jrow[r * ld + C] = e[r];
       }
     } else {
       atomicOr(dc.status, st);
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, De
   }
   Jacc = wave_sum(Jacc);
   if (lane == 0) dc.Jpart[jpart_base + blockIdx.x] = Jacc;
-  if (!dc.build) return;
+  if (!BUILD) return;
   __syncthreads();
   if (dc.build == 3) return;
   if (dc.build == 2) {
@@ -895,7 +910,7 @@ void mc_context::uploadStructure() {
       L.n_items = (int)chunks[l].size();
       L.n_jpart = L.n_items;
       StreamDims& dm = L.dims;
-      dm.ld = (36 + dm.maxG + 1) | 1;
+      dm.ld = (36 + ((dm.maxG + 1 + 6) / 7) * 7 + 1) & ~1;   // other columns + residual padded to whole 7-column tiles; even (16-byte aligned pairs)
       const int dim = l == LAUNCH_IMU ? 3 : 1;
       size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + 6 * dm.maxNb + (dm.maxNb + 1) + ((size_t)dm.maxNob * dm.maxNb + 1) +
                     ((size_t)dm.maxNob * dm.maxNob + 1) + (dm.maxNob + 1) + (dm.maxG + 1);
@@ -903,9 +918,9 @@ void mc_context::uploadStructure() {
       if (L.lds_bytes > 150 * 1024) throw std::runtime_error("chunk tile exceeds the LDS budget");
       if (L.lds_bytes > 64 * 1024) {
         if (l == LAUNCH_LIDAR)
-          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<LidarBatchView>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<LidarBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
         else
-          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<ImuBatchView>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<ImuBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
       }
     } else {
       L.groups.upload(groups[l]);
@@ -942,16 +957,20 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     if (L.n_items == 0) continue;
     switch (l) {
       case LAUNCH_REPROJ:
-        hipLaunchKernelGGL(k_reproj, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.jpart_base);
+        if (build) hipLaunchKernelGGL(k_reproj<true>, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.jpart_base);
+        else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.jpart_base);
         break;
       case LAUNCH_STATIC:
-        hipLaunchKernelGGL(k_group<StaticReprojBatchView>, dim3(L.n_items), dim3(64), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.jpart_base);
+        if (build) hipLaunchKernelGGL((k_group<StaticReprojBatchView, true>), dim3(L.n_items), dim3(64), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.jpart_base);
+        else hipLaunchKernelGGL((k_group<StaticReprojBatchView, false>), dim3(L.n_items), dim3(64), 0, st, L.sviews.p, dc, L.groups.p, L.jpart_base);
         break;
       case LAUNCH_IMU:
-        hipLaunchKernelGGL(k_stream<ImuBatchView>, dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        if (build) hipLaunchKernelGGL((k_stream<ImuBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else hipLaunchKernelGGL((k_stream<ImuBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_LIDAR:
-        hipLaunchKernelGGL(k_stream<LidarBatchView>, dim3(L.n_items), dim3(256), L.lds_bytes, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        if (build) hipLaunchKernelGGL((k_stream<LidarBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else hipLaunchKernelGGL((k_stream<LidarBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_MOTION:
         hipLaunchKernelGGL(k_motion, dim3(L.motion_blocks, L.n_items), dim3(256), 0, st, L.mviews.p, dc, L.jpart_base);

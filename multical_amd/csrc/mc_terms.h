@@ -133,9 +133,9 @@ MC_HD void f1_common(const ReprojBatchView& b, const double* x, int obs, F1Commo
   rigid_mul(cm.Tcb, Tbw, cm.X);
   rigid_mul(cm.X, Twp, cm.Tcp);
 }
-// One corner: weighted core rows (2 x 19, row-major) and weighted residual e[2].
+// One corner: weighted core rows (2 x 19, row stride ld) and weighted residual e[2].
 MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,
-                   double* core, double* e, TermOut& out) {
+                   double* core, int ld, double* e, TermOut& out) {
   const double* pt = b.p + 3 * (size_t)k;
   double pc[3];
   m3_mulv(cm.Tcp.C, pt, pc);
@@ -152,7 +152,7 @@ MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm
   if (!wantJ) return;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    double* row = core + r * F1_CORE;
+    double* row = core + r * ld;   // the kernel points this straight at its LDS tile
     // A0 = -J_cam; through HomogeneousExpressionNodeMultiply: A1 = A0 * boxMinus(p_c) = [a, a x p_c]
     double a[3] = {-sw * Jc[3 * r], -sw * Jc[3 * r + 1], -sw * Jc[3 * r + 2]};
     double ap[3];

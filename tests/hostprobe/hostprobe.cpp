@@ -137,7 +137,7 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     f1_common(v, x, obs, cm);
     if (!cm.ok) throw std::runtime_error("time out of spline");
     double core[2 * F1_CORE], ee[2];
-    f1_term(v, x, cm, k, useM != 0, true, core, ee, out);
+    f1_term(v, x, cm, k, useM != 0, true, core, F1_CORE, ee, out);
     rolecol[F1_ROLE_COEF] = v.sp.first_col >= 0 ? v.sp.first_col + 6 * cm.ps.seg : -1;
     rolecol[F1_ROLE_QCB] = v.q_cb.col; rolecol[F1_ROLE_TCB] = v.t_cb.col;
     rolecol[F1_ROLE_QPW] = col(B.obs_dv_q[obs]); rolecol[F1_ROLE_TPW] = col(B.obs_dv_t[obs]); rolecol[F1_ROLE_TOFF] = v.toff.col;
