@@ -54,6 +54,7 @@ struct ChunkRec {
   int pose_lo, pose_nb;        // coefficient range laid out for the chunk (0 blocks if the pose spline is inactive)
   int ofp;                     // "other blocks" footprint id
   int batch;                   // index into the launch's view array (set when the launch list is built)
+  int tab_off, tab_len;        // this chunk's slot table in Problem::chunk_tab (built for this rank's chunks)
 };
 
 struct Batch {
@@ -79,7 +80,7 @@ struct Batch {
   std::vector<int> order, term_lo, term_nbuf;
   std::vector<ChunkRec> chunks, my_chunks;
   std::vector<double> chunk_time;
-  int max_nb = 0, max_nob = 0, max_g = 0, max_terms = 0;   // over my_chunks: sizes the kernel's LDS
+  int max_nb = 0, max_nob = 0, max_g = 0, max_terms = 0, max_tab = 0;   // over my_chunks: sizes the kernel's LDS
   // SURVEY 8(d) accounting (filled by finalize)
   double flops_dense = 0, flops_live = 0;
 };
@@ -97,7 +98,8 @@ enum { CHUNK_TERMS_LIDAR = 128, CHUNK_TERMS_IMU = 32, CHUNK_WINDOW = 40, CHUNK_B
 //   [4 .. 4+MC_MAX_ROLES) rolecol
 //   then nb x (block index, local col start, block dim, global column base)
 //   then nb(nb+1)/2 slot bases, pair (ia <= ib) at ib(ib+1)/2 + ia
-//   then C bytes-as-ints: block position of each local column
+//   then C ints: block position of each local column
+//   then nb ints: col_h of each block
 enum { FP_HDR = 4 + MC_MAX_ROLES };
 
 struct Problem {
@@ -123,7 +125,15 @@ struct Problem {
   std::vector<int> update_dvs;              // active dvs in block order
   std::vector<int> ofp_data, ofp_off;       // other-block footprints of the chunks
   std::map<std::vector<int>, int> ofp_lookup;
-  std::vector<int> pat_colptr, pat_rows, pat_roff, pat_cp0;   // block pattern as CSR for device-side slot lookups
+  std::vector<int> pat_colptr, pat_rows, pat_roff, pat_cp0;   // block pattern as CSR
+  // Slot tables of this rank's chunks, one contiguous record per chunk (copied to LDS by one coalesced read):
+  //   band[nb*6]   value offset of coefficient block pair (bj - d, bj) at [bj*6 + d], -1 if absent
+  //   hcol[nb]     col_h of coefficient block bj
+  //   arrow[nob*nb] value offset of (other block o, coefficient block b) in whichever order the pattern stores it
+  //   oo[nob*nob]  value offset of other-block pair (o1, o2) when block(o1) <= block(o2), else -1
+  //   oh[nob]      col_h of other block o
+  //   ocolblk[G]   other block of each local other column
+  std::vector<int> chunk_tab;
 
   // ------------------------------------------------------------------ description
   int addDv(int kind, const double* params, int n, int active, double scaling) {
@@ -431,7 +441,7 @@ inline void Problem::finalize() {
         }
         int ofp = internOtherFootprint(written, biasLo, biasN);
         bool poseActive = coef_block0 >= 0;
-        b.chunks.push_back(ChunkRec{c_first, c_count, poseActive ? c_lo : 0, poseActive ? c_hi - c_lo + 1 : 0, ofp, 0});
+        b.chunks.push_back(ChunkRec{c_first, c_count, poseActive ? c_lo : 0, poseActive ? c_hi - c_lo + 1 : 0, ofp, 0, 0, 0});
         b.chunk_time.push_back(c_time);
         c_count = 0;
       };
@@ -595,7 +605,9 @@ inline void Problem::finalize() {
       for (int ia = 0; ia <= ib; ++ia) fp_data.push_back(slotBase(blocks[ia].first, blocks[ib].first));
     for (int i = 0; i < nb; ++i)
       for (int c = colstart[i]; c < colstart[i + 1]; ++c) fp_data.push_back(i);
+    for (int i = 0; i < nb; ++i) fp_data.push_back(col_h[blocks[i].first]);   // column height of each block (address stride)
   }
+  fp_off.push_back((int)fp_data.size());   // sentinel: footprint f spans [fp_off[f], fp_off[f+1])
   // ---- shard: contiguous time windows of equal estimated cost over all groups
   {
     struct GT { double t; double cost; };
@@ -627,10 +639,37 @@ inline void Problem::finalize() {
         if (b.group_time[g] >= shard_lo && b.group_time[g] < shard_hi) mine.push_back(b.groups[g]);
       b.my_groups.swap(mine);
       b.my_chunks.clear();
-      b.max_nb = b.max_nob = b.max_g = b.max_terms = 0;
+      b.max_nb = b.max_nob = b.max_g = b.max_terms = b.max_tab = 0;
+      const int pose_block0 = (b.spline >= 0 && !b.chunks.empty()) ? dvs[splines[b.spline].first_dv].block : -1;
       for (size_t g = 0; g < b.chunks.size(); ++g)
         if (b.chunk_time[g] >= shard_lo && b.chunk_time[g] < shard_hi) {
-          const ChunkRec& c = b.chunks[g];
+          ChunkRec c = b.chunks[g];
+          {
+            const int* of = &ofp_data[ofp_off[c.ofp]];
+            const int nob = of[0], G = of[1], nb = c.pose_nb, pb = pose_block0 + c.pose_lo;
+            const int* ob = of + OFP_HDR;
+            auto lookup = [&](int rb, int cb) {
+              const std::vector<int>& rows = col_rows[cb];
+              auto it = std::lower_bound(rows.begin(), rows.end(), rb);
+              return (it != rows.end() && *it == rb) ? Cp[block_col[cb]] + col_roff[cb][it - rows.begin()] : -1;
+            };
+            c.tab_off = (int)chunk_tab.size();
+            for (int bj = 0; bj < nb; ++bj)
+              for (int d = 0; d < 6; ++d) chunk_tab.push_back(bj - d >= 0 ? lookup(pb + bj - d, pb + bj) : -1);
+            for (int bj = 0; bj < nb; ++bj) chunk_tab.push_back(col_h[pb + bj]);
+            for (int o = 0; o < nob; ++o)
+              for (int bj = 0; bj < nb; ++bj) {
+                int obk = ob[4 * o], pk = pb + bj;
+                chunk_tab.push_back(obk < pk ? lookup(obk, pk) : lookup(pk, obk));
+              }
+            for (int o1 = 0; o1 < nob; ++o1)
+              for (int o2 = 0; o2 < nob; ++o2) chunk_tab.push_back(ob[4 * o1] <= ob[4 * o2] ? lookup(ob[4 * o1], ob[4 * o2]) : -1);
+            for (int o = 0; o < nob; ++o) chunk_tab.push_back(col_h[ob[4 * o]]);
+            for (int o = 0; o < nob; ++o) for (int cc = 0; cc < ob[4 * o + 1]; ++cc) chunk_tab.push_back(o);
+            (void)G;
+            c.tab_len = (int)chunk_tab.size() - c.tab_off;
+            b.max_tab = std::max(b.max_tab, c.tab_len);
+          }
           b.my_chunks.push_back(c);
           b.max_nb = std::max(b.max_nb, c.pose_nb);
           b.max_nob = std::max(b.max_nob, ofp_data[ofp_off[c.ofp]]);

@@ -36,6 +36,7 @@ struct DevCommon {
   const int* pat_rows;
   const int* pat_roff;
   const int* pat_cp0;
+  const int* chunk_tab;  // per-chunk slot tables (Problem::chunk_tab)
   double* Cx;
   double* rhs;
   double* e;        // may be null
@@ -60,24 +61,26 @@ struct FpView {
   const int* blocks;   // nb x (block index, local col start, dim, global column base)
   const int* slots;    // nb(nb+1)/2
   const int* colblk;   // C
+  const int* h;        // nb: col_h of each block
 };
-__device__ __forceinline__ FpView fp_view(const DevCommon& dc, int fp) {
-  const int* d = dc.fp_data + dc.fp_off[fp];
+// d points at the footprint table (global memory, or a copy staged in LDS)
+__device__ __forceinline__ FpView fp_view_at(const int* d) {
   FpView v;
   v.nb = d[0]; v.C = d[1]; v.coef_lo = d[2]; v.nbuf = d[3];
   v.rolecol = d + 4;
   v.blocks = d + FP_HDR;
   v.slots = v.blocks + 4 * v.nb;
   v.colblk = v.slots + (v.nb * (v.nb + 1)) / 2;
+  v.h = v.colblk + v.C;
   return v;
 }
+__device__ __forceinline__ FpView fp_view(const DevCommon& dc, int fp) { return fp_view_at(dc.fp_data + dc.fp_off[fp]); }
 // value index of Hessian entry (local columns ca <= cb) in the CCS array:
 // slot(ia, ib) + rb * h(ib) + rb (rb + 1) / 2 + ra     (see Problem::finalize for the layout)
-__device__ __forceinline__ int entry_addr(const FpView& f, const int* col_h, int ca, int cb) {
+__device__ __forceinline__ int entry_addr(const FpView& f, const int*, int ca, int cb) {
   int ia = f.colblk[ca], ib = f.colblk[cb];
   int ra = ca - f.blocks[4 * ia + 1], rb = cb - f.blocks[4 * ib + 1];
-  int h = col_h[f.blocks[4 * ib]];
-  return f.slots[(ib * (ib + 1)) / 2 + ia] + rb * h + (rb * (rb + 1)) / 2 + ra;
+  return f.slots[(ib * (ib + 1)) / 2 + ia] + rb * f.h[ib] + (rb * (rb + 1)) / 2 + ra;
 }
 __device__ __forceinline__ int global_col(const FpView& f, int ca) {
   int ia = f.colblk[ca];
@@ -88,84 +91,144 @@ __device__ __forceinline__ int global_col(const FpView& f, int ca) {
 // F1: one wave per image observation.  Every corner of the image shares the spline sample, so the
 // per-corner work is a 2 x 19 "core" row pair; the wave reduces the 20 x 20 core Gram matrix (column 19 is
 // the weighted residual) and expands it to the 6 live coefficient blocks with the basis weights.
-enum { F1_LD = F1_CORE + 2 };  // 21: odd stride, conflict-free column reads
+// F1 pre-pass: one LANE per image observation computes what all its corners share (spline sample at t + d, the
+// transformation chain prefixes).  Done inside k_reproj this would be repeated by every lane of the workgroup -- as
+// many flops as the corners themselves.
+__global__ __launch_bounds__(64) void k_obs_common(const ReprojBatchView* __restrict__ views, const double* __restrict__ x,
+                                                   const GroupRec* __restrict__ groups, int n, F1Common* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const GroupRec gr = groups[g];
+  F1Common cm;
+  f1_common(views[gr.batch], x, gr.aux, cm);
+  out[g] = cm;
+}
+
+enum { F1_LD = F1_CORE + 2, F1_ROWS = 256 };  // 21: odd stride, conflict-free column reads; 128 corners per pass
 template <bool BUILD>
-__global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
-                                               const GroupRec* __restrict__ groups, int jpart_base) {
-  __shared__ double rows[128 * F1_LD];
+__global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
+                                                const GroupRec* __restrict__ groups, const F1Common* __restrict__ common,
+                                                int jpart_base) {
+  // One 256-thread workgroup per image observation; thread = one residual ROW (two threads per corner), so the
+  // Jacobian phase, the 20 x 20 core Gram (one entry per thread) and the expansion all run four waves wide.
+  __shared__ double rows[F1_ROWS * F1_LD];
   __shared__ double Msh[210];
   __shared__ int glc[13], gk[13];
   __shared__ int nglob;
-  const int lane = threadIdx.x;
+  __shared__ double red[4];
+  // the per-image quantities (k_obs_common) are uniform over the workgroup: parked in LDS and read back by
+  // broadcast so they do not occupy ~110 vector registers per lane
+  __shared__ F1Common cm;
+  // the footprint table (block list, value offsets of every block pair) is staged too: the expansion below turns
+  // ~1600 (column, column) pairs into addresses and would otherwise chase 3 dependent global loads per pair
+  enum { FP_LDS = 768 };
+  __shared__ int fpl[FP_LDS];
+  const int tid = threadIdx.x;
   const GroupRec gr = groups[blockIdx.x];
   const ReprojBatchView b = views[gr.batch];
-  // the per-image quantities (spline sample, transformation chain prefix) are wave-uniform: computed once, parked in
-  // LDS and read back by broadcast so they do not occupy ~190 vector registers per lane
-  __shared__ F1Common cm;
-  f1_common(b, dc.x, gr.aux, cm);   // every lane stores the same values (single-wave workgroup)
+  const int fp_begin = dc.fp_off[gr.fp], fp_len = dc.fp_off[gr.fp + 1] - fp_begin;
+  const bool fp_staged = BUILD && fp_len <= FP_LDS;
+  {
+    static_assert(sizeof(F1Common) % 8 == 0, "F1Common is copied as doubles");
+    const double* src = reinterpret_cast<const double*>(common + blockIdx.x);
+    double* dst = reinterpret_cast<double*>(&cm);
+    if (tid < (int)(sizeof(F1Common) / 8)) dst[tid] = src[tid];
+    if (fp_staged) for (int i = tid; i < fp_len; i += 256) fpl[i] = dc.fp_data[fp_begin + i];
+  }
   __syncthreads();
   if (!cm.ok) {
-    if (lane == 0) { atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
+    if (tid == 0) { atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
     return;
   }
-  FpView f = fp_view(dc, gr.fp);
+  FpView f = fp_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + fp_begin);
   const int rc0 = f.rolecol[F1_ROLE_COEF];
   int coef_shift = 0;
   if (rc0 >= 0) {
     // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
-    coef_shift = cm.ps.seg - f.coef_lo;
+    coef_shift = cm.seg - f.coef_lo;
     if (coef_shift < 0 || coef_shift + S6 > f.nbuf) {
-      if (lane == 0) { atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
+      if (tid == 0) { atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
       return;
     }
   }
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0};
   double Jacc = 0.0;
-  double macc[4] = {0.0, 0.0, 0.0, 0.0};
-  int ea[4], eb[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {  // entry idx -> (a <= b) of the 20 x 20 upper triangle, idx = b(b+1)/2 + a
-    int idx = lane + 64 * q;
-    int bb = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
-    while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
-    while (bb * (bb + 1) / 2 > idx) --bb;
-    ea[q] = idx - bb * (bb + 1) / 2; eb[q] = bb;
+  double macc = 0.0;
+  int ea = 0, eb = 0;
+  if (tid < 210) {  // entry idx -> (a <= b) of the 20 x 20 upper triangle, idx = b(b+1)/2 + a
+    int bb = (int)((sqrtf(8.0f * tid + 1.0f) - 1.0f) * 0.5f);
+    while ((bb + 1) * (bb + 2) / 2 <= tid) ++bb;
+    while (bb * (bb + 1) / 2 > tid) --bb;
+    ea = tid - bb * (bb + 1) / 2; eb = bb;
   }
-  for (int base = 0; base < gr.term_count; base += 64) {
-    const int k = base + lane;
-    const int nk = min(64, gr.term_count - base);
+  // build: two threads per corner (one residual row each); evaluate only: one thread per corner
+  constexpr int CPP = BUILD ? F1_ROWS / 2 : F1_ROWS;   // corners per pass
+  const int r = BUILD ? (tid & 1) : 0;
+  for (int base = 0; base < gr.term_count; base += CPP) {
+    const int k = base + (BUILD ? (tid >> 1) : tid);
+    const int nrows = 2 * min(CPP, gr.term_count - base);
     if (k < gr.term_count) {
-      double e[2];
-      TermOut out;
       const int term = gr.term_first + k;
-      double* row = rows + (2 * lane) * F1_LD;
       const F1Common* cmp = &cm;
-      asm volatile("" : "+v"(cmp));   // keeps the per-image block in LDS (otherwise its loads are hoisted into ~100 VGPRs)
-      f1_term(b, dc.x, *cmp, term, dc.useM != 0, BUILD, row, F1_LD, e, out);
-      Jacc += out.w * out.chi2;
-      dc.chi2[b.term_base_global + term] = out.chi2;
-      if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
-      if (BUILD) { row[F1_CORE] = e[0]; row[F1_LD + F1_CORE] = e[1]; }
+      double pc[3], Jc[6], e[2], sw;
+      TermOut out;
+      f1_project(b, dc.x, *cmp, term, dc.useM != 0, BUILD, pc, Jc, e, sw, out);
+      const double er = r ? e[1] : e[0];
+      if (r == 0) { Jacc += out.w * out.chi2; dc.chi2[b.term_base_global + term] = out.chi2; }
+      if (dc.e) {
+        if (BUILD) dc.e[b.row_base + 2 * term + r] = -er;
+        else { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
+      }
+      if (BUILD) {
+        double jc[3] = {r ? Jc[3] : Jc[0], r ? Jc[4] : Jc[1], r ? Jc[5] : Jc[2]};
+        double* row = rows + tid * F1_LD;
+        f1_chain_row(b, *cmp, jc, sw, pc, row);
+        row[F1_CORE] = er;
+      }
     }
     if (BUILD) {
+      // 20 x 20 core Gram R^T R on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A[i][k] = R[k][i] and
+      // B[k][j] = R[k][j] one double per lane (lane = 16 (k % 4) + column), so a K-step of 4 rows costs two LDS reads
+      // and three MFMAs (column tiles 0..15 and 16..19: blocks 00, 01, 11).  The 4 waves take every 4th K-step.
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (lane + 64 * q < 210) {
-          double s = 0.0;
-          for (int r = 0; r < 2 * nk; ++r) s += rows[r * F1_LD + ea[q]] * rows[r * F1_LD + eb[q]];
-          macc[q] += s;
-        }
+      const int lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
+      const int nsteps = (nrows + 3) >> 2;
+      for (int st = tid >> 6; st < nsteps; st += 4) {
+        const int rr = 4 * st + kr;
+        double v0 = 0.0, v1 = 0.0;
+        if (rr < nrows) { v0 = rows[rr * F1_LD + c16]; if (c16 < 4) v1 = rows[rr * F1_LD + 16 + c16]; }
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc11, 0, 0, 0);
       }
       __syncthreads();
     }
   }
-  Jacc = wave_sum(Jacc);
-  if (lane == 0) dc.Jpart[jpart_base + blockIdx.x] = Jacc;
-  if (!BUILD) return;
-  if (dc.build == 3) { if (macc[0] == 1.2345e-300) dc.rhs[0] = 1.0; return; }
+  if (BUILD) {
+    // per-wave partial tiles -> LDS (aliasing the row tile, which is dead now) -> one entry per thread.
+    // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
+    double* stage = rows;   // [wave][tile][reg][lane]
+    const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) if (lane + 64 * q < 210) Msh[lane + 64 * q] = macc[q];
-  if (lane == 0) {
+    for (int rg = 0; rg < 4; ++rg) {
+      stage[((wv * 3 + 0) * 4 + rg) * 64 + lane] = acc00[rg];
+      stage[((wv * 3 + 1) * 4 + rg) * 64 + lane] = acc01[rg];
+      stage[((wv * 3 + 2) * 4 + rg) * 64 + lane] = acc11[rg];
+    }
+    __syncthreads();
+    if (tid < 210) {
+      const int t = ea >= 16 ? 2 : (eb >= 16 ? 1 : 0);
+      const int i = ea & 15, j = eb & 15;
+      const int off = (t * 4 + (i >> 2)) * 64 + (i & 3) * 16 + j;
+      macc = stage[off] + stage[off + 768] + stage[off + 2 * 768] + stage[off + 3 * 768];
+    }
+    __syncthreads();
+  }
+  Jacc = wave_sum(Jacc);
+  if ((tid & 63) == 0) red[tid >> 6] = Jacc;
+  if (BUILD && tid < 210) Msh[tid] = macc;
+  if (BUILD && tid == 0) {
     int n = 0;
     for (int g = 0; g < 4; ++g)
       if (f.rolecol[1 + g] >= 0) for (int d = 0; d < 3; ++d) { glc[n] = f.rolecol[1 + g] + d; gk[n] = 6 + 3 * g + d; ++n; }
@@ -173,19 +236,22 @@ __global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict
     nglob = n;
   }
   __syncthreads();
+  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (!BUILD) return;
+  if (dc.build == 3) return;
   const int ncoef = rc0 >= 0 ? 36 : 0;
   const int nlive = ncoef + nglob;
   const int npair = nlive * (nlive + 1) / 2;
-  for (int idx = lane; idx < npair; idx += 64) {
+  for (int idx = tid; idx < npair; idx += 256) {
     int q = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
     while ((q + 1) * (q + 2) / 2 <= idx) ++q;
     while (q * (q + 1) / 2 > idx) --q;
     int p = idx - q * (q + 1) / 2;
     int lcp, kp_, lcq, kq_;
     double wp, wq;
-    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.ps.w[0][i]; }
+    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.w[i]; }
     else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
-    if (q < ncoef) { int i = q / 6; kq_ = q - 6 * i; lcq = rc0 + 6 * (coef_shift + i) + kq_; wq = cm.ps.w[0][i]; }
+    if (q < ncoef) { int i = q / 6; kq_ = q - 6 * i; lcq = rc0 + 6 * (coef_shift + i) + kq_; wq = cm.w[i]; }
     else { lcq = glc[q - ncoef]; kq_ = gk[q - ncoef]; wq = 1.0; }
     int ka = min(kp_, kq_), kb = max(kp_, kq_);
     double v = wp * wq * Msh[kb * (kb + 1) / 2 + ka];
@@ -193,10 +259,10 @@ __global__ __launch_bounds__(64) void k_reproj(const ReprojBatchView* __restrict
     int addr = entry_addr(f, dc.col_h, ca, cb);
     if (dc.build == 1 || v == 1.2345e-300) atomic_add_f64(dc.Cx + addr, v);
   }
-  for (int p = lane; p < nlive; p += 64) {
+  for (int p = tid; p < nlive; p += 256) {
     int lcp, kp_;
     double wp;
-    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.ps.w[0][i]; }
+    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.w[i]; }
     else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
     atomic_add_f64(dc.rhs + global_col(f, lcp), -wp * Msh[19 * 20 / 2 + kp_]);
   }
@@ -230,7 +296,7 @@ __device__ __forceinline__ int b_pose_first_col(const ImuBatchView& b) { return 
 //            atomic per entry; entries are enumerated down the CCS columns so a wave's adds are contiguous runs.
 // Compared with one group per footprint this cuts the atomics by the number of terms that share a window and keeps
 // every lane busy in both phases.
-struct StreamDims { int maxT, maxNb, maxNob, maxG, ld; };
+struct StreamDims { int maxT, maxNb, maxNob, maxG, ld, maxTab; };
 template <class View> struct StreamBatch {
   View v;
   const int* order;      // time-sorted term order of the batch
@@ -315,34 +381,20 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
   int* beta0 = ip; ip += dm.maxT;
   int* rlo = ip; ip += dm.maxNb + 1;
   int* rhi = ip; ip += dm.maxNb + 1;
-  int* band_slot = ip; ip += dm.maxNb * 6;
-  int* hcol = ip; ip += dm.maxNb + 1;
-  int* arrow_slot = ip; ip += dm.maxNob * dm.maxNb + 1;
-  int* oo_slot = ip; ip += dm.maxNob * dm.maxNob + 1;
-  int* oh = ip; ip += dm.maxNob + 1;
-  int* ocolblk = ip; ip += dm.maxG + 1;
+  // the chunk's slot table (Problem::chunk_tab), staged by one coalesced read
+  int* tab = ip;
+  const int* band_slot = tab;
+  const int* hcol = band_slot + nb * 6;
+  const int* arrow_slot = hcol + nb;
+  const int* oo_slot = arrow_slot + nob * nb;
+  const int* oh = oo_slot + nob * nob;
+  const int* ocolblk = oh + nob;
   __shared__ double red[4];
   constexpr bool build = BUILD;
   if (build) {
     for (int i = tid; i < T * D * ld; i += 256) rows[i] = 0.0;
     for (int i = tid; i <= nb; i += 256) { rlo[i] = 0x7fffffff; rhi[i] = 0; }
-    for (int i = tid; i < nb * 6; i += 256) {
-      int bj = i / 6, bi = bj - (i % 6);
-      band_slot[i] = bi >= 0 ? slot_lookup(dc, pb + bi, pb + bj) : -1;
-    }
-    for (int i = tid; i < nb; i += 256) hcol[i] = dc.col_h[pb + i];
-    for (int i = tid; i < nob * nb; i += 256) {
-      int ob = oblk[4 * (i / nb)], pk = pb + (i % nb);
-      arrow_slot[i] = ob < pk ? slot_lookup(dc, ob, pk) : slot_lookup(dc, pk, ob);
-    }
-    for (int i = tid; i < nob * nob; i += 256) {
-      int b1 = oblk[4 * (i / nob)], b2 = oblk[4 * (i % nob)];
-      oo_slot[i] = b1 <= b2 ? slot_lookup(dc, b1, b2) : -1;
-    }
-    for (int i = tid; i < nob; i += 256) {
-      oh[i] = dc.col_h[oblk[4 * i]];
-      for (int c = 0; c < oblk[4 * i + 1]; ++c) ocolblk[oblk[4 * i + 2] + c] = i;
-    }
+    for (int i = tid; i < ch.tab_len; i += 256) tab[i] = dc.chunk_tab[ch.tab_off + i];
     __syncthreads();
   }
   // ---- phase 1: one term per thread
@@ -685,7 +737,7 @@ enum { LAUNCH_REPROJ = 0, LAUNCH_STATIC = 1, LAUNCH_IMU = 2, LAUNCH_LIDAR = 3, L
 struct LaunchUnit {
   int n_batches = 0, n_terms = 0, n_items = 0, jpart_base = 0, n_jpart = 0, lds_bytes = 0;
   double flops_dense = 0, flops_live = 0, rec_bytes = 0;
-  StreamDims dims{0, 0, 0, 0, 0};
+  StreamDims dims{0, 0, 0, 0, 0, 0};
   int motion_blocks = 0;
   DevBuf<GroupRec> groups;
   DevBuf<ChunkRec> chunks;
@@ -694,6 +746,7 @@ struct LaunchUnit {
   DevBuf<StreamBatch<ImuBatchView>> iviews;
   DevBuf<StreamBatch<LidarBatchView>> lviews;
   DevBuf<MotionView> mviews;
+  DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
 };
 
 }  // namespace mc
@@ -705,7 +758,7 @@ struct mc_context {
   std::string err;
   int device = 0;
   DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, Jpart2, J, dx;
-  DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0;
+  DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab;
   DevBuf<UpdRec> upd;
   std::vector<std::unique_ptr<DevBatch>> db;
   LaunchUnit lu[N_LAUNCH];
@@ -765,6 +818,7 @@ void mc_context::uploadStructure() {
   col_h.upload(P.col_h);
   ofp_data.upload(P.ofp_data); ofp_off.upload(P.ofp_off);
   pat_colptr.upload(P.pat_colptr); pat_rows.upload(P.pat_rows); pat_roff.upload(P.pat_roff); pat_cp0.upload(P.pat_cp0);
+  chunk_tab.upload(P.chunk_tab);
   status.alloc(1);
   Cx.alloc(P.nnz); rhs.alloc(P.j_cols); e.alloc(P.j_rows); chi2.alloc(P.n_terms); J.alloc(1); dx.alloc(P.j_cols);
   std::vector<UpdRec> ur;
@@ -800,6 +854,7 @@ void mc_context::uploadStructure() {
       StreamDims& dm = L.dims;
       dm.maxT = std::max(dm.maxT, b.max_terms); dm.maxNb = std::max(dm.maxNb, b.max_nb);
       dm.maxNob = std::max(dm.maxNob, b.max_nob); dm.maxG = std::max(dm.maxG, b.max_g);
+      dm.maxTab = std::max(dm.maxTab, b.max_tab);
     } else if (b.kind != KIND_MOTION) {
       int maxR = 0, maxC = 0;
       for (GroupRec g : b.my_groups) {
@@ -912,8 +967,7 @@ void mc_context::uploadStructure() {
       StreamDims& dm = L.dims;
       dm.ld = (36 + ((dm.maxG + 1 + 6) / 7) * 7 + 1) & ~1;   // other columns + residual padded to whole 7-column tiles; even (16-byte aligned pairs)
       const int dim = l == LAUNCH_IMU ? 3 : 1;
-      size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + 6 * dm.maxNb + (dm.maxNb + 1) + ((size_t)dm.maxNob * dm.maxNb + 1) +
-                    ((size_t)dm.maxNob * dm.maxNob + 1) + (dm.maxNob + 1) + (dm.maxG + 1);
+      size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + dm.maxTab + 4;
       L.lds_bytes = (int)((size_t)dm.maxT * dim * dm.ld * sizeof(double) + ints * sizeof(int) + 16);
       if (L.lds_bytes > 150 * 1024) throw std::runtime_error("chunk tile exceeds the LDS budget");
       if (L.lds_bytes > 64 * 1024) {
@@ -926,6 +980,7 @@ void mc_context::uploadStructure() {
       L.groups.upload(groups[l]);
       L.n_items = (int)groups[l].size();
       L.n_jpart = L.n_items;
+      if (l == LAUNCH_REPROJ) L.common.alloc(groups[l].size());
     }
     n_jpart += L.n_jpart;
   }
@@ -944,6 +999,7 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   dc.x = x.p; dc.fp_data = fp_data.p; dc.fp_off = fp_off.p; dc.col_h = col_h.p;
   dc.ofp_data = ofp_data.p; dc.ofp_off = ofp_off.p;
   dc.pat_colptr = pat_colptr.p; dc.pat_rows = pat_rows.p; dc.pat_roff = pat_roff.p; dc.pat_cp0 = pat_cp0.p;
+  dc.chunk_tab = chunk_tab.p;
   dc.Cx = dCx; dc.rhs = dRhs; dc.e = dE; dc.chi2 = chi2.p; dc.Jpart = Jpart.p; dc.status = status.p;
   dc.useM = useM; dc.build = build;
   if (build) {
@@ -957,8 +1013,9 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     if (L.n_items == 0) continue;
     switch (l) {
       case LAUNCH_REPROJ:
-        if (build) hipLaunchKernelGGL(k_reproj<true>, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.jpart_base);
-        else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.jpart_base);
+        hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p);
+        if (build) hipLaunchKernelGGL(k_reproj<true>, dim3(L.n_items), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.common.p, L.jpart_base);
+        else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_items), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.common.p, L.jpart_base);
         break;
       case LAUNCH_STATIC:
         if (build) hipLaunchKernelGGL((k_group<StaticReprojBatchView, true>), dim3(L.n_items), dim3(64), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.jpart_base);

@@ -64,12 +64,12 @@ MC_HD bool pose_sample(const SplineView& sp, const double* x, double t, PoseSamp
   return true;
 }
 // [u v] * JT,  JT = [I, -r^ S; 0, S]  (BSplinePose.cpp:402-407)  ->  [u, (v - u x r) S]
-MC_HD void chain_JT(const double* u, const double* v, const PoseSample& ps, double* B) {
+MC_HD void chain_JT(const double* u, const double* v, const double* r, const double* S, double* B) {
   double c[3], wv[3];
-  v3_cross(u, ps.c, c);
+  v3_cross(u, r, c);
   wv[0] = v[0] - c[0]; wv[1] = v[1] - c[1]; wv[2] = v[2] - c[2];
   B[0] = u[0]; B[1] = u[1]; B[2] = u[2];
-  m3_tmulv(ps.S, wv, B + 3);
+  m3_tmulv(S, wv, B + 3);
 }
 // TransformationBasic leaves (ABE/src/TransformationBasic.cpp:48-67): chain [u v] ->
 //   translation block = u ;  rotation block = v - u x r
@@ -111,76 +111,92 @@ struct ReprojBatchView {
   int row_base;   // row base of term 0 of this batch
   int term_base_global;  // global index of term 0 of this batch
 };
+// what every corner of one image observation shares (computed once per observation by k_obs_common)
 struct F1Common {
-  PoseSample ps;
-  Rigid Tcb, Tcp, X;   // T_c_b, T_c_p = X * T_w_p, X = T_c_b * T_b_w
-  double rpw[3];
-  bool ok;
+  Rigid Tcp, X;        // T_c_p = X * T_w_p, X = T_c_b * T_b_w
+  double rcb[3];       // translation of T_c_b
+  double rpw[3];       // translation of T_p_w
+  double r[3], S[9];   // body position and S(theta) at t + d
+  double cd[6];        // time derivative of the spline value
+  double w[S6];        // basis weights of the 6 live coefficients
+  int seg, ok;
 };
 MC_HD void f1_common(const ReprojBatchView& b, const double* x, int obs, F1Common& cm) {
   double t = b.obs_time[obs] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
-  cm.ok = pose_sample<2>(b.sp, x, t, cm.ps);
+  PoseSample ps;
+  cm.ok = pose_sample<2>(b.sp, x, t, ps) ? 1 : 0;
+  cm.seg = ps.seg;
   if (!cm.ok) return;
-  load_rigid(x, b.q_cb.off, b.t_cb.off, cm.Tcb);
-  Rigid Twb, Tbw, Tpw, Twp;
+  Rigid Tcb, Twb, Tbw, Tpw, Twp;
+  load_rigid(x, b.q_cb.off, b.t_cb.off, Tcb);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) Twb.C[i] = cm.ps.C[i];
-  Twb.r[0] = cm.ps.c[0]; Twb.r[1] = cm.ps.c[1]; Twb.r[2] = cm.ps.c[2];
+  for (int i = 0; i < 9; ++i) { Twb.C[i] = ps.C[i]; cm.S[i] = ps.S[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { Twb.r[i] = ps.c[i]; cm.r[i] = ps.c[i]; cm.rcb[i] = Tcb.r[i]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { cm.cd[i] = ps.cd[i]; cm.w[i] = ps.w[0][i]; }
   rigid_inv(Twb, Tbw);
   load_rigid(x, b.obs_qpw_off[obs], b.obs_tpw_off[obs], Tpw);
   cm.rpw[0] = Tpw.r[0]; cm.rpw[1] = Tpw.r[1]; cm.rpw[2] = Tpw.r[2];
   rigid_inv(Tpw, Twp);
-  rigid_mul(cm.Tcb, Tbw, cm.X);
+  rigid_mul(Tcb, Tbw, cm.X);
   rigid_mul(cm.X, Twp, cm.Tcp);
 }
-// One corner: weighted core rows (2 x 19, row stride ld) and weighted residual e[2].
-MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,
-                   double* core, int ld, double* e, TermOut& out) {
+// One corner, first half: camera-frame point, projection (+ 2x3 Jacobian), weighted residual e[2], sw = sqrt(w) * s.
+MC_HD void f1_project(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,
+                      double* pc, double* Jc, double* e, double& sw, TermOut& out) {
   const double* pt = b.p + 3 * (size_t)k;
-  double pc[3];
   m3_mulv(cm.Tcp.C, pt, pc);
   pc[0] += cm.Tcp.r[0]; pc[1] += cm.Tcp.r[1]; pc[2] += cm.Tcp.r[2];
-  double kp[2], Jc[6];
+  double kp[2];
   project(b.cam.model, b.cam.dist, x + b.cam.proj_off, b.cam.dist_off >= 0 ? x + b.cam.dist_off : x, pc, kp,
           wantJ ? Jc : nullptr);
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
   double s = b.sinv[k];
   out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
   out.w = mest_weight(b.mest, b.mest_a, out.chi2);
-  double sw = (useM ? sqrt(out.w) : 1.0) * s;
+  sw = (useM ? sqrt(out.w) : 1.0) * s;
   e[0] = sw * e0; e[1] = sw * e1;
-  if (!wantJ) return;
+}
+// One corner, second half: one weighted core row (19 values) from one row jc[3] of the projection Jacobian.
+MC_HD void f1_chain_row(const ReprojBatchView& b, const F1Common& cm, const double* jc, double sw, const double* pc, double* row) {
+  // A0 = -J_cam; through HomogeneousExpressionNodeMultiply: A1 = A0 * boxMinus(p_c) = [a, a x p_c]
+  double a[3] = {-sw * jc[0], -sw * jc[1], -sw * jc[2]};
+  double ap[3];
+  v3_cross(a, pc, ap);
+  // lhs of (X * T_w_p), lhs of (T_c_b * T_b_w): TransformationBasic(q_c_b, t_c_b)
+  chain_basic(a, ap, cm.rcb, row + 6, row + 9);
+  // rhs T_w_p = inverse(T_p_w): chain * boxTimes(X) * (-boxTimes(T_w_p)) = -chain * boxTimes(T_c_p)
+  double u[3], v[3];
+  chain_boxtimes(a, ap, cm.Tcp, u, v);
+  u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
+  chain_basic(u, v, cm.rpw, row + 12, row + 15);
+  // rhs T_b_w = inverse(T_w_b): chain * boxTimes(T_c_b) * (-boxTimes(T_b_w)) = -chain * boxTimes(X)
+  chain_boxtimes(a, ap, cm.X, u, v);
+  u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
+  double B[6];
+  chain_JT(u, v, cm.r, cm.S, B);
+  // time offset: B * (Phi_dot c)  (BSplineExpressions.cpp:538-541)
+  double jd = 0;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    double* row = core + r * ld;   // the kernel points this straight at its LDS tile
-    // A0 = -J_cam; through HomogeneousExpressionNodeMultiply: A1 = A0 * boxMinus(p_c) = [a, a x p_c]
-    double a[3] = {-sw * Jc[3 * r], -sw * Jc[3 * r + 1], -sw * Jc[3 * r + 2]};
-    double ap[3];
-    v3_cross(a, pc, ap);
-    // lhs of (X * T_w_p), lhs of (T_c_b * T_b_w): TransformationBasic(q_c_b, t_c_b)
-    chain_basic(a, ap, cm.Tcb.r, row + 6, row + 9);
-    // rhs T_w_p = inverse(T_p_w): chain * boxTimes(X) * (-boxTimes(T_w_p)) = -chain * boxTimes(T_c_p)
-    double u[3], v[3];
-    chain_boxtimes(a, ap, cm.Tcp, u, v);
-    u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
-    chain_basic(u, v, cm.rpw, row + 12, row + 15);
-    // rhs T_b_w = inverse(T_w_b): chain * boxTimes(T_c_b) * (-boxTimes(T_b_w)) = -chain * boxTimes(X)
-    chain_boxtimes(a, ap, cm.X, u, v);
-    u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
-    chain_JT(u, v, cm.ps, row);
-    // time offset: B * (Phi_dot c)  (BSplineExpressions.cpp:538-541)
-    double jd = 0;
+  for (int d = 0; d < 6; ++d) jd += B[d] * cm.cd[d];
+  row[18] = jd * b.toff.scale;
 #pragma unroll
-    for (int d = 0; d < 6; ++d) jd += row[d] * cm.ps.cd[d];
-    row[18] = jd * b.toff.scale;
+  for (int d = 0; d < 6; ++d) row[d] = B[d] * b.coef_scale;
 #pragma unroll
-    for (int d = 0; d < 6; ++d) row[d] *= b.coef_scale;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      row[6 + d] *= b.q_cb.scale; row[9 + d] *= b.t_cb.scale;
-      row[12 + d] *= b.qpw_scale; row[15 + d] *= b.tpw_scale;
-    }
+  for (int d = 0; d < 3; ++d) {
+    row[6 + d] *= b.q_cb.scale; row[9 + d] *= b.t_cb.scale;
+    row[12 + d] *= b.qpw_scale; row[15 + d] *= b.tpw_scale;
   }
+}
+// One corner: weighted core rows (2 x 19, row stride ld) and weighted residual e[2].
+MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,
+                   double* core, int ld, double* e, TermOut& out) {
+  double pc[3], Jc[6], sw;
+  f1_project(b, x, cm, k, useM, wantJ, pc, Jc, e, sw, out);
+  if (!wantJ) return;
+  f1_chain_row(b, cm, Jc, sw, pc, core);
+  f1_chain_row(b, cm, Jc + 3, sw, pc, core + ld);
 }
 // expand one core row into a (sorted / dense) Jacobian row
 MC_HD void f1_expand_row(const double* core, const double* w, const int* rolecol, double* Jrow) {
@@ -256,7 +272,7 @@ MC_HD bool f5_term(const LidarBatchView& b, const double* x, int k, bool useM, b
   chain_boxtimes(u, v, Tpw, u2, v2);
   // lhs T_w_b: time-offset spline node
   double B[6];
-  chain_JT(u2, v2, ps, B);
+  chain_JT(u2, v2, ps.c, ps.S, B);
   if (rolecol[F5_ROLE_COEF] >= 0)
     for (int i = 0; i < S6; ++i)
       for (int c = 0; c < 6; ++c) J[rolecol[F5_ROLE_COEF] + 6 * i + c] = ps.w[0][i] * B[c] * b.coef_scale;

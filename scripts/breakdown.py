@@ -14,10 +14,11 @@ spec, H = synth.build_spec(W, synth.initial_state(W), meas)
 api = HipApi(0); spec.emit(api); api.finalize()
 info = api.launch_info()
 res = {}
-for mode in (0, 3, 2, 1):
+MODES = tuple(int(m) for m in os.environ.get('MC_MODES', '0,3,2,1').split(','))
+for mode in MODES:
     for _ in range(2): api.build_system_timed(True, mode)
     res[mode] = np.mean([api.build_system_timed(True, mode) for _ in range(5)], axis=0)
 for i, (name, nbatch, nt, nwg, fd, fl, rb) in enumerate(info):
-    print("%-22s batches %3d terms %8d workgroups %7d (%.1f terms/wg) | eval %.3f  jac %.3f  +gram %.3f  full %.3f ms" %
-          (name, nbatch, nt, nwg, nt / max(1, nwg), res[0][i], res[3][i], res[2][i], res[1][i]))
+    print("%-22s batches %3d terms %8d workgroups %7d (%.1f terms/wg) | " % (name, nbatch, nt, nwg, nt / max(1, nwg)) +
+          "  ".join("%s %.3f" % ({0: "eval", 3: "jac", 2: "+gram", 1: "full"}[m], res[m][i]) for m in MODES) + " ms")
 print("total: " + "  ".join("mode%d %.3f" % (m, float(res[m].sum())) for m in res))

@@ -138,10 +138,10 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     if (!cm.ok) throw std::runtime_error("time out of spline");
     double core[2 * F1_CORE], ee[2];
     f1_term(v, x, cm, k, useM != 0, true, core, F1_CORE, ee, out);
-    rolecol[F1_ROLE_COEF] = v.sp.first_col >= 0 ? v.sp.first_col + 6 * cm.ps.seg : -1;
+    rolecol[F1_ROLE_COEF] = v.sp.first_col >= 0 ? v.sp.first_col + 6 * cm.seg : -1;
     rolecol[F1_ROLE_QCB] = v.q_cb.col; rolecol[F1_ROLE_TCB] = v.t_cb.col;
     rolecol[F1_ROLE_QPW] = col(B.obs_dv_q[obs]); rolecol[F1_ROLE_TPW] = col(B.obs_dv_t[obs]); rolecol[F1_ROLE_TOFF] = v.toff.col;
-    for (int r = 0; r < 2; ++r) { f1_expand_row(core + r * F1_CORE, cm.ps.w[0], rolecol, Jd + (size_t)r * JC); e[r] = ee[r]; }
+    for (int r = 0; r < 2; ++r) { f1_expand_row(core + r * F1_CORE, cm.w, rolecol, Jd + (size_t)r * JC); e[r] = ee[r]; }
   } else if (B.kind == KIND_LIDAR) {
     LidarBatchView v;
     v.sp = P.splineView(B.spline, P.knots.data(), P.basis.data());
