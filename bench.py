@@ -123,8 +123,19 @@ def main():
     tf_dense = pk["flops_dense"] / (pk["ms"] * 1e-3) / 1e12
     tf_live = pk["flops_live"] / (pk["ms"] * 1e-3) / 1e12
     gbs = alg_bytes / (pk["ms"] * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: from the committed rocprofv3 PMC passes of this same command (separate runs,
+    # FETCH_SIZE x2 corrected; scripts/profile_bench.sh + scripts/summarize_profile.py) -- counters cannot be read in-process
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    if world == 1 and args.config == 3 and args.duration is None and os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        if dom in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom]["fetch"] + tj["kernels"][dom]["write"]
+            traffic_src = "profiles/%s_pmc_hbm_traffic.csv" % tj["tag"]
     roofline = dict(bound="mfma", kernel=dom, achieved=round(tf_dense, 4), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(tf_dense / FP64_PEAK_TFLOPS, 5), traffic=None,
+                    frac=round(tf_dense / FP64_PEAK_TFLOPS, 5), traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_bytes=round(alg_bytes),
                     note="fp64 vector/matrix peak; 'achieved' counts the reference's dense per-term J^T J flops (SURVEY 8d)",
                     achieved_live_flops=round(tf_live, 4), frac_live=round(tf_live / FP64_PEAK_TFLOPS, 5),
                     hbm_achieved_gbs=round(gbs, 2), hbm_frac=round(gbs / HBM_PEAK_GBS, 5),

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restric
         if (BUILD) dc.e[b.row_base + 2 * term + r] = -er;
         else { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
       }
-      if (BUILD) {
+      if (BUILD && dc.build != 4) {
         double jc[3] = {r ? Jc[3] : Jc[0], r ? Jc[4] : Jc[1], r ? Jc[5] : Jc[2]};
         double* row = rows + tid * F1_LD;
         f1_chain_row(b, *cmp, jc, sw, pc, row);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restric
       // and three MFMAs (column tiles 0..15 and 16..19: blocks 00, 01, 11).  The 4 waves take every 4th K-step.
       __syncthreads();
       const int lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
-      const int nsteps = (nrows + 3) >> 2;
+      const int nsteps = (dc.build == 4 || dc.build == 5) ? 0 : (nrows + 3) >> 2;
       for (int st = tid >> 6; st < nsteps; st += 4) {
         const int rr = 4 * st + kr;
         double v0 = 0.0, v1 = 0.0;

@@ -20,5 +20,5 @@ for mode in MODES:
     res[mode] = np.mean([api.build_system_timed(True, mode) for _ in range(5)], axis=0)
 for i, (name, nbatch, nt, nwg, fd, fl, rb) in enumerate(info):
     print("%-22s batches %3d terms %8d workgroups %7d (%.1f terms/wg) | " % (name, nbatch, nt, nwg, nt / max(1, nwg)) +
-          "  ".join("%s %.3f" % ({0: "eval", 3: "jac", 2: "+gram", 1: "full"}[m], res[m][i]) for m in MODES) + " ms")
+          "  ".join("%s %.3f" % ({0: "eval", 3: "jac", 2: "+gram", 1: "full", 4: "m4", 5: "m5"}[m], res[m][i]) for m in MODES) + " ms")
 print("total: " + "  ".join("mode%d %.3f" % (m, float(res[m].sum())) for m in res))

@@ -36,3 +36,16 @@ with open(os.path.join("profiles", tag + "_pmc_hbm_traffic.csv"), "w") as f:
         w.writerow([k, a["n"], round(a["fetch"] / n, 2), round(2 * a["fetch"] / n * 1024 / 1e6, 3), round(a["write"] / n, 2),
                     round(a["write"] / n * 1024 / 1e6, 3), a["vgpr"], a["lds"], a["scratch"]])
 print(open(os.path.join("profiles", tag + "_pmc_hbm_traffic.csv")).read())
+
+# per-launch HBM bytes (fetch x2 + write) of the buildSystem kernels, for bench.py's roofline.traffic
+import json
+short = {"k_reproj<true>": "k_reproj", "k_stream<mc::ImuBatchView, true>": "k_stream<Imu>", "k_stream<mc::LidarBatchView, true>": "k_stream<Lidar>",
+         "k_motion(": "k_motion", "k_group<mc::StaticReprojBatchView, true>": "k_group<StaticReproj>"}
+out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline", "unit": "bytes per launch", "kernels": {}}
+for k, a in agg.items():
+    for pat, name in short.items():
+        if pat in k:
+            n = max(1, a["n"])
+            out["kernels"][name] = dict(fetch=2 * a["fetch"] / n * 1024, write=a["write"] / n * 1024)
+with open(os.path.join("profiles", "hbm_traffic_latest.json"), "w") as f:
+    json.dump(out, f, indent=1)
