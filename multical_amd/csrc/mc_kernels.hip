@@ -105,140 +105,14 @@ __global__ __launch_bounds__(64) void k_obs_common(const ReprojBatchView* __rest
 }
 
 enum { F1_LD = F1_CORE + 2, F1_ROWS = 256 };  // 21: odd stride, conflict-free column reads; 128 corners per pass
-template <bool BUILD>
-__global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
-                                                const GroupRec* __restrict__ groups, const F1Common* __restrict__ common,
-                                                int jpart_base) {
-  // One 256-thread workgroup per image observation; thread = one residual ROW (two threads per corner), so the
-  // Jacobian phase, the 20 x 20 core Gram (one entry per thread) and the expansion all run four waves wide.
-  __shared__ double rows[F1_ROWS * F1_LD];
-  __shared__ double Msh[210];
-  __shared__ int glc[13], gk[13];
-  __shared__ int nglob;
-  __shared__ double red[4];
-  // the per-image quantities (k_obs_common) are uniform over the workgroup: parked in LDS and read back by
-  // broadcast so they do not occupy ~110 vector registers per lane
-  __shared__ F1Common cm;
-  // the footprint table (block list, value offsets of every block pair) is staged too: the expansion below turns
-  // ~1600 (column, column) pairs into addresses and would otherwise chase 3 dependent global loads per pair
-  enum { FP_LDS = 768 };
-  __shared__ int fpl[FP_LDS];
-  const int tid = threadIdx.x;
-  const GroupRec gr = groups[blockIdx.x];
-  const ReprojBatchView b = views[gr.batch];
-  const int fp_begin = dc.fp_off[gr.fp], fp_len = dc.fp_off[gr.fp + 1] - fp_begin;
-  const bool fp_staged = BUILD && fp_len <= FP_LDS;
-  {
-    static_assert(sizeof(F1Common) % 8 == 0, "F1Common is copied as doubles");
-    const double* src = reinterpret_cast<const double*>(common + blockIdx.x);
-    double* dst = reinterpret_cast<double*>(&cm);
-    if (tid < (int)(sizeof(F1Common) / 8)) dst[tid] = src[tid];
-    if (fp_staged) for (int i = tid; i < fp_len; i += 256) fpl[i] = dc.fp_data[fp_begin + i];
-  }
-  __syncthreads();
-  if (!cm.ok) {
-    if (tid == 0) { atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
-    return;
-  }
-  FpView f = fp_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + fp_begin);
-  const int rc0 = f.rolecol[F1_ROLE_COEF];
-  int coef_shift = 0;
-  if (rc0 >= 0) {
-    // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
-    coef_shift = cm.seg - f.coef_lo;
-    if (coef_shift < 0 || coef_shift + S6 > f.nbuf) {
-      if (tid == 0) { atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); dc.Jpart[jpart_base + blockIdx.x] = 0.0; }
-      return;
-    }
-  }
-  typedef double f64x4 __attribute__((ext_vector_type(4)));
-  f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0};
-  double Jacc = 0.0;
-  double macc = 0.0;
-  int ea = 0, eb = 0;
-  if (tid < 210) {  // entry idx -> (a <= b) of the 20 x 20 upper triangle, idx = b(b+1)/2 + a
-    int bb = (int)((sqrtf(8.0f * tid + 1.0f) - 1.0f) * 0.5f);
-    while ((bb + 1) * (bb + 2) / 2 <= tid) ++bb;
-    while (bb * (bb + 1) / 2 > tid) --bb;
-    ea = tid - bb * (bb + 1) / 2; eb = bb;
-  }
-  // build: two threads per corner (one residual row each); evaluate only: one thread per corner
-  constexpr int CPP = BUILD ? F1_ROWS / 2 : F1_ROWS;   // corners per pass
-  const int r = BUILD ? (tid & 1) : 0;
-  for (int base = 0; base < gr.term_count; base += CPP) {
-    const int k = base + (BUILD ? (tid >> 1) : tid);
-    const int nrows = 2 * min(CPP, gr.term_count - base);
-    if (k < gr.term_count) {
-      const int term = gr.term_first + k;
-      const F1Common* cmp = &cm;
-      double pc[3], Jc[6], e[2], sw;
-      TermOut out;
-      f1_project(b, dc.x, *cmp, term, dc.useM != 0, BUILD, pc, Jc, e, sw, out);
-      const double er = r ? e[1] : e[0];
-      if (r == 0) { Jacc += out.w * out.chi2; dc.chi2[b.term_base_global + term] = out.chi2; }
-      if (dc.e) {
-        if (BUILD) dc.e[b.row_base + 2 * term + r] = -er;
-        else { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
-      }
-      if (BUILD && dc.build != 4) {
-        double jc[3] = {r ? Jc[3] : Jc[0], r ? Jc[4] : Jc[1], r ? Jc[5] : Jc[2]};
-        double* row = rows + tid * F1_LD;
-        f1_chain_row(b, *cmp, jc, sw, pc, row);
-        row[F1_CORE] = er;
-      }
-    }
-    if (BUILD) {
-      // 20 x 20 core Gram R^T R on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A[i][k] = R[k][i] and
-      // B[k][j] = R[k][j] one double per lane (lane = 16 (k % 4) + column), so a K-step of 4 rows costs two LDS reads
-      // and three MFMAs (column tiles 0..15 and 16..19: blocks 00, 01, 11).  The 4 waves take every 4th K-step.
-      __syncthreads();
-      const int lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
-      const int nsteps = (dc.build == 4 || dc.build == 5) ? 0 : (nrows + 3) >> 2;
-      for (int st = tid >> 6; st < nsteps; st += 4) {
-        const int rr = 4 * st + kr;
-        double v0 = 0.0, v1 = 0.0;
-        if (rr < nrows) { v0 = rows[rr * F1_LD + c16]; if (c16 < 4) v1 = rows[rr * F1_LD + 16 + c16]; }
-        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, acc01, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc11, 0, 0, 0);
-      }
-      __syncthreads();
-    }
-  }
-  if (BUILD) {
-    // per-wave partial tiles -> LDS (aliasing the row tile, which is dead now) -> one entry per thread.
-    // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
-    double* stage = rows;   // [wave][tile][reg][lane]
-    const int wv = tid >> 6, lane = tid & 63;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      stage[((wv * 3 + 0) * 4 + rg) * 64 + lane] = acc00[rg];
-      stage[((wv * 3 + 1) * 4 + rg) * 64 + lane] = acc01[rg];
-      stage[((wv * 3 + 2) * 4 + rg) * 64 + lane] = acc11[rg];
-    }
-    __syncthreads();
-    if (tid < 210) {
-      const int t = ea >= 16 ? 2 : (eb >= 16 ? 1 : 0);
-      const int i = ea & 15, j = eb & 15;
-      const int off = (t * 4 + (i >> 2)) * 64 + (i & 3) * 16 + j;
-      macc = stage[off] + stage[off + 768] + stage[off + 2 * 768] + stage[off + 3 * 768];
-    }
-    __syncthreads();
-  }
-  Jacc = wave_sum(Jacc);
-  if ((tid & 63) == 0) red[tid >> 6] = Jacc;
-  if (BUILD && tid < 210) Msh[tid] = macc;
-  if (BUILD && tid == 0) {
-    int n = 0;
-    for (int g = 0; g < 4; ++g)
-      if (f.rolecol[1 + g] >= 0) for (int d = 0; d < 3; ++d) { glc[n] = f.rolecol[1 + g] + d; gk[n] = 6 + 3 * g + d; ++n; }
-    if (f.rolecol[F1_ROLE_TOFF] >= 0) { glc[n] = f.rolecol[F1_ROLE_TOFF]; gk[n] = 18; ++n; }
-    nglob = n;
-  }
-  __syncthreads();
-  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-  if (!BUILD) return;
-  if (dc.build == 3) return;
+// consecutive observations (groups) of one camera taken at the same time: one image seeing several boards
+struct ImageRec { int first, count; };
+
+// Expansion of a 20 x 20 core Gram (Msh, upper triangle, idx = b(b+1)/2 + a; column 19 = residual) to Hessian entries:
+// core columns 0..5 fan out to the 6 live coefficient blocks with the basis weights, the others map 1:1.
+// board_part selects the pairs that involve a board-pose column (core 12..17) or those that do not.
+__device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, const double* Msh, const double* w, int rc0,
+                                         int coef_shift, const int* glc, const int* gk, int nglob, bool board_part, int tid) {
   const int ncoef = rc0 >= 0 ? 36 : 0;
   const int nlive = ncoef + nglob;
   const int npair = nlive * (nlive + 1) / 2;
@@ -249,10 +123,12 @@ __global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restric
     int p = idx - q * (q + 1) / 2;
     int lcp, kp_, lcq, kq_;
     double wp, wq;
-    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.w[i]; }
+    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = w[i]; }
     else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
-    if (q < ncoef) { int i = q / 6; kq_ = q - 6 * i; lcq = rc0 + 6 * (coef_shift + i) + kq_; wq = cm.w[i]; }
+    if (q < ncoef) { int i = q / 6; kq_ = q - 6 * i; lcq = rc0 + 6 * (coef_shift + i) + kq_; wq = w[i]; }
     else { lcq = glc[q - ncoef]; kq_ = gk[q - ncoef]; wq = 1.0; }
+    const bool brd = (kp_ >= 12 && kp_ <= 17) || (kq_ >= 12 && kq_ <= 17);
+    if (brd != board_part) continue;
     int ka = min(kp_, kq_), kb = max(kp_, kq_);
     double v = wp * wq * Msh[kb * (kb + 1) / 2 + ka];
     int ca = min(lcp, lcq), cb = max(lcp, lcq);
@@ -262,10 +138,165 @@ __global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restric
   for (int p = tid; p < nlive; p += 256) {
     int lcp, kp_;
     double wp;
-    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = cm.w[i]; }
+    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = w[i]; }
     else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
-    atomic_add_f64(dc.rhs + global_col(f, lcp), -wp * Msh[19 * 20 / 2 + kp_]);
+    const bool brd = kp_ >= 12 && kp_ <= 17;
+    if (brd != board_part) continue;
+    double v = -wp * Msh[19 * 20 / 2 + kp_];
+    if (dc.build == 1 || v == 1.2345e-300) atomic_add_f64(dc.rhs + global_col(f, lcp), v);
   }
+}
+
+template <bool BUILD>
+__global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
+                                                const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
+                                                const F1Common* __restrict__ common, int jpart_base) {
+  // One 256-thread workgroup per IMAGE; its observations (one per visible board) are processed one after the other.
+  // build: thread = one residual ROW (two threads per corner), so the Jacobian phase, the 20 x 20 core Gram and the
+  // expansion all run four waves wide.  The observations of an image share time, camera and extrinsics, so the part of
+  // their core Gram that does not involve the board pose is summed over the image and flushed ONCE; only the board
+  // rows / columns are flushed per observation (about 3x fewer atomics at ~4 boards per image).
+  __shared__ double rows[F1_ROWS * F1_LD];
+  __shared__ double Msh[210];
+  __shared__ int glc[13], gk[13];
+  __shared__ int nglob;
+  __shared__ double red[4];
+  // the per-observation quantities (k_obs_common) are uniform over the workgroup: parked in LDS and read back by
+  // broadcast so they do not occupy ~110 vector registers per lane
+  __shared__ F1Common cm;
+  // the footprint table (block list, value offsets of every block pair) is staged too: the expansion turns
+  // ~1600 (column, column) pairs into addresses and would otherwise chase 3 dependent global loads per pair
+  enum { FP_LDS = 768 };
+  __shared__ int fpl[FP_LDS];
+  const int tid = threadIdx.x;
+  const ImageRec im = images[blockIdx.x];
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  double Jacc = 0.0;
+  double img_acc = 0.0;     // this thread's entry of the image-level (non-board) core Gram
+  int ea = 0, eb = 0;
+  if (tid < 210) {  // entry idx -> (a <= b) of the 20 x 20 upper triangle, idx = b(b+1)/2 + a
+    int bb = (int)((sqrtf(8.0f * tid + 1.0f) - 1.0f) * 0.5f);
+    while ((bb + 1) * (bb + 2) / 2 <= tid) ++bb;
+    while (bb * (bb + 1) / 2 > tid) --bb;
+    ea = tid - bb * (bb + 1) / 2; eb = bb;
+  }
+  const bool my_board_entry = (ea >= 12 && ea <= 17) || (eb >= 12 && eb <= 17);
+  bool any_done = false;
+  int last_rc0 = -1, last_shift = 0;
+  bool last_staged = false;
+  int last_fp_begin = 0;
+  // build: two threads per corner (one residual row each); evaluate only: one thread per corner
+  constexpr int CPP = BUILD ? F1_ROWS / 2 : F1_ROWS;   // corners per pass
+  const int r = BUILD ? (tid & 1) : 0;
+  for (int go = 0; go < im.count; ++go) {
+    const int gi = im.first + go;
+    any_done = false;   // the image-level flush below needs the LAST observation's tables intact
+    const GroupRec gr = groups[gi];
+    const ReprojBatchView b = views[gr.batch];
+    const int fp_begin = dc.fp_off[gr.fp], fp_len = dc.fp_off[gr.fp + 1] - fp_begin;
+    const bool fp_staged = BUILD && fp_len <= FP_LDS;
+    __syncthreads();   // previous observation's flush is done with cm / fpl / Msh
+    {
+      static_assert(sizeof(F1Common) % 8 == 0, "F1Common is copied as doubles");
+      const double* src = reinterpret_cast<const double*>(common + gi);
+      double* dst = reinterpret_cast<double*>(&cm);
+      if (tid < (int)(sizeof(F1Common) / 8)) dst[tid] = src[tid];
+      if (fp_staged) for (int i = tid; i < fp_len; i += 256) fpl[i] = dc.fp_data[fp_begin + i];
+    }
+    __syncthreads();
+    if (!cm.ok) { if (tid == 0) atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); continue; }
+    FpView f = fp_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + fp_begin);
+    const int rc0 = f.rolecol[F1_ROLE_COEF];
+    int coef_shift = 0;
+    if (rc0 >= 0) {
+      // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
+      coef_shift = cm.seg - f.coef_lo;
+      if (coef_shift < 0 || coef_shift + S6 > f.nbuf) { if (tid == 0) atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); continue; }
+    }
+    f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < gr.term_count; base += CPP) {
+      const int k = base + (BUILD ? (tid >> 1) : tid);
+      const int nrows = 2 * min(CPP, gr.term_count - base);
+      if (k < gr.term_count) {
+        const int term = gr.term_first + k;
+        double pc[3], Jc[6], e[2], sw;
+        TermOut out;
+        f1_project(b, dc.x, cm, term, dc.useM != 0, BUILD, pc, Jc, e, sw, out);
+        const double er = r ? e[1] : e[0];
+        if (r == 0) { Jacc += out.w * out.chi2; dc.chi2[b.term_base_global + term] = out.chi2; }
+        if (dc.e) {
+          if (BUILD) dc.e[b.row_base + 2 * term + r] = -er;
+          else { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
+        }
+        if (BUILD) {
+          double jc[3] = {r ? Jc[3] : Jc[0], r ? Jc[4] : Jc[1], r ? Jc[5] : Jc[2]};
+          double* row = rows + tid * F1_LD;
+          f1_chain_row(b, cm, jc, sw, pc, row);
+          row[F1_CORE] = er;
+        }
+      }
+      if (BUILD) {
+        // 20 x 20 core Gram R^T R on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A[i][k] = R[k][i] and
+        // B[k][j] = R[k][j] one double per lane (lane = 16 (k % 4) + column), so a K-step of 4 rows costs two LDS
+        // reads and three MFMAs (column tiles 0..15 and 16..19: blocks 00, 01, 11).  The 4 waves take every 4th K-step.
+        __syncthreads();
+        const int lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
+        const int nsteps = (nrows + 3) >> 2;
+        for (int st = tid >> 6; st < nsteps; st += 4) {
+          const int rr = 4 * st + kr;
+          double v0 = 0.0, v1 = 0.0;
+          if (rr < nrows) { v0 = rows[rr * F1_LD + c16]; if (c16 < 4) v1 = rows[rr * F1_LD + 16 + c16]; }
+          acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc00, 0, 0, 0);
+          acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, acc01, 0, 0, 0);
+          acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc11, 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    }
+    if (BUILD) {
+      // per-wave partial tiles -> LDS (aliasing the row tile, which is dead now) -> one entry per thread.
+      // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
+      double* stage = rows;   // [wave][tile][reg][lane]
+      const int wv = tid >> 6, lane = tid & 63;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        stage[((wv * 3 + 0) * 4 + rg) * 64 + lane] = acc00[rg];
+        stage[((wv * 3 + 1) * 4 + rg) * 64 + lane] = acc01[rg];
+        stage[((wv * 3 + 2) * 4 + rg) * 64 + lane] = acc11[rg];
+      }
+      if (tid == 0) {
+        int n = 0;
+        for (int g = 0; g < 4; ++g)
+          if (f.rolecol[1 + g] >= 0) for (int d = 0; d < 3; ++d) { glc[n] = f.rolecol[1 + g] + d; gk[n] = 6 + 3 * g + d; ++n; }
+        if (f.rolecol[F1_ROLE_TOFF] >= 0) { glc[n] = f.rolecol[F1_ROLE_TOFF]; gk[n] = 18; ++n; }
+        nglob = n;
+      }
+      __syncthreads();
+      if (tid < 210) {
+        const int t = ea >= 16 ? 2 : (eb >= 16 ? 1 : 0);
+        const int i = ea & 15, j = eb & 15;
+        const int off = (t * 4 + (i >> 2)) * 64 + (i & 3) * 16 + j;
+        const double m = stage[off] + stage[off + 768] + stage[off + 2 * 768] + stage[off + 3 * 768];
+        Msh[tid] = m;
+        if (!my_board_entry) img_acc += m;
+      }
+      __syncthreads();
+      // board rows / columns of this observation
+      if (dc.build != 3) f1_flush(f, dc, Msh, cm.w, rc0, coef_shift, glc, gk, nglob, true, tid);
+      any_done = true; last_rc0 = rc0; last_shift = coef_shift; last_staged = fp_staged; last_fp_begin = fp_begin;
+    }
+  }
+  Jacc = wave_sum(Jacc);
+  if ((tid & 63) == 0) red[tid >> 6] = Jacc;
+  __syncthreads();
+  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (!BUILD || !any_done || dc.build == 3) return;
+  // image-level part: everything that does not involve a board pose, through the last observation's footprint
+  // (same camera, same time: same coefficient buffer, extrinsics and time-offset blocks)
+  if (tid < 210) Msh[tid] = img_acc;
+  __syncthreads();
+  FpView f = last_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + last_fp_begin);
+  f1_flush(f, dc, Msh, cm.w, last_rc0, last_shift, glc, gk, nglob, false, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -747,6 +778,8 @@ struct LaunchUnit {
   DevBuf<StreamBatch<LidarBatchView>> lviews;
   DevBuf<MotionView> mviews;
   DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
+  DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time
+  int n_images = 0;
 };
 
 }  // namespace mc
@@ -832,6 +865,7 @@ void mc_context::uploadStructure() {
   std::vector<StreamBatch<ImuBatchView>> iviews;
   std::vector<StreamBatch<LidarBatchView>> lviews;
   std::vector<MotionView> mviews;
+  std::vector<ImageRec> images;
   for (int l = 0; l < N_LAUNCH; ++l) lu[l] = LaunchUnit();
   int term_base = 0;
   for (Batch& b : P.batches) {
@@ -857,9 +891,18 @@ void mc_context::uploadStructure() {
       dm.maxTab = std::max(dm.maxTab, b.max_tab);
     } else if (b.kind != KIND_MOTION) {
       int maxR = 0, maxC = 0;
+      double last_time = 0;
+      bool first_of_batch = true;
       for (GroupRec g : b.my_groups) {
         if (g.term_count == 0) continue;
         g.batch = view_index;
+        if (b.kind == KIND_REPROJ) {
+          // observations of one camera at one time form an image (they share everything but the board pose)
+          double tg = b.t[g.aux];
+          if (first_of_batch || tg != last_time || images.back().count >= 16) images.push_back(ImageRec{(int)groups[li].size(), 0});
+          images.back().count++;
+          last_time = tg; first_of_batch = false;
+        }
         groups[li].push_back(g);
         maxR = std::max(maxR, g.term_count * b.dim); maxC = std::max(maxC, P.fp_data[P.fp_off[g.fp] + 1]);
       }
@@ -980,7 +1023,12 @@ void mc_context::uploadStructure() {
       L.groups.upload(groups[l]);
       L.n_items = (int)groups[l].size();
       L.n_jpart = L.n_items;
-      if (l == LAUNCH_REPROJ) L.common.alloc(groups[l].size());
+      if (l == LAUNCH_REPROJ) {
+        L.common.alloc(groups[l].size());
+        L.images.upload(images);
+        L.n_images = (int)images.size();
+        L.n_jpart = L.n_images;
+      }
     }
     n_jpart += L.n_jpart;
   }
@@ -1014,8 +1062,8 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     switch (l) {
       case LAUNCH_REPROJ:
         hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p);
-        if (build) hipLaunchKernelGGL(k_reproj<true>, dim3(L.n_items), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.common.p, L.jpart_base);
-        else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_items), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.common.p, L.jpart_base);
+        if (build) hipLaunchKernelGGL(k_reproj<true>, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
+        else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
         break;
       case LAUNCH_STATIC:
         if (build) hipLaunchKernelGGL((k_group<StaticReprojBatchView, true>), dim3(L.n_items), dim3(64), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.jpart_base);
@@ -1211,7 +1259,7 @@ int mc_launch_info(const mc_context* ctx, int launch, int* n_batches, int* n_ter
   const LaunchUnit& L = ctx->lu[launch];
   if (n_batches) *n_batches = L.n_batches;
   if (n_terms) *n_terms = L.n_terms;
-  if (n_workgroups) *n_workgroups = launch == LAUNCH_MOTION ? L.n_items * L.motion_blocks : L.n_items;
+  if (n_workgroups) *n_workgroups = launch == LAUNCH_MOTION ? L.n_items * L.motion_blocks : (launch == LAUNCH_REPROJ ? L.n_images : L.n_items);
   return 0;
 }
 int mc_launch_counts(const mc_context* ctx, int launch, double* flops_dense, double* flops_live, double* record_bytes) {
