@@ -68,11 +68,18 @@ def main():
     dJ = torch.zeros(1, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    n_shared = len(api.shared_indices()) if world > 1 else 0
+    dshared = torch.zeros(max(1, n_shared), dtype=torch.float64, device=dev)
+
     def step():
         api.evaluate_error_device(True, dJ.data_ptr(), None, stream)
         api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), stream)
         if world > 1:
-            dist.all_reduce(dCx)
+            # partial Hessians: only the entries two ranks can write (window halos, global x global blocks) are summed;
+            # every other entry already sits complete on the rank that owns its time window
+            api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
+            dist.all_reduce(dshared)
+            api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
             dist.all_reduce(drhs)
             dist.all_reduce(dJ)
 
@@ -150,7 +157,8 @@ def main():
                            % (args.config, cfg.n_imus, cfg.n_cams, cfg.n_lidars, cfg.n_boards, per_gpu),
                            error_terms=n_terms, j_rows=api.j_rows, j_cols=api.j_cols, nnz_upper=api.nnz, n_blocks=api.n_blocks,
                            build_ms=round(float(ms_build.sum()), 4), evaluate_ms=round(float(ms_eval.sum()), 4),
-                           setup_s=round(t_setup, 2), sharding="time windows, global pattern, all-reduce of Cx/rhs/J" if world > 1 else "none"),
+                           setup_s=round(t_setup, 2), shared_values=n_shared,
+                           sharding="time windows, global pattern; RCCL all-reduce of rhs, J and the Cx entries shared between ranks" if world > 1 else "none"),
                roofline=roofline)
 
     if args.solve and rank == 0:

@@ -109,6 +109,17 @@ int mc_add_motion_term(mc_context* ctx, int spline, const double* W, int error_t
  * only parallelism is boost threads over term ranges (LinearSystemSolver.cpp:50-78). */
 int mc_set_shard(mc_context* ctx, int rank, int world);
 
+/* With shards, only the value entries that more than one rank's terms can write need summing over ranks: the halos of
+ * the coefficient band at the window boundaries and the blocks between global design variables (a few 10^5 values,
+ * against 10^7..10^8 in the whole array).  After mc_finalize: their count, their (sorted) indices into Cx -- identical
+ * on every rank --, and gather / scatter between a device Cx array and a compact device buffer, enqueued on `stream`:
+ * pack -> all-reduce(buffer) -> unpack.  Every other entry of Cx is non-zero on exactly one rank (its owner); rhs and J
+ * are summed whole.  No counterpart in the reference. */
+int mc_shared_count(const mc_context* ctx);
+int mc_get_shared_indices(const mc_context* ctx, int* out);
+int mc_pack_shared(mc_context* ctx, const double* d_Cx, double* d_buf, void* stream);
+int mc_unpack_shared(mc_context* ctx, const double* d_buf, double* d_Cx, void* stream);
+
 /* LinearSystemSolver::initMatrixStructure + BlockCholeskyLinearSystemSolver::initMatrixStructureImplementation
  * (LinearSystemSolver.cpp:117-138, BlockCholeskyLinearSystemSolver.cpp:34-55) plus the symbolic part of
  * SparseBlockMatrix::fillCCS (sparse_block_matrix.hpp:704-729): assigns block indices / column bases to

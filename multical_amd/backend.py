@@ -188,6 +188,19 @@ class HipApi(object):
         if s:
             raise BackendError(self.lib.mc_last_error(self.ctx).decode())
 
+    def shared_indices(self):
+        n = self.lib.mc_shared_count(self.ctx)
+        out = np.zeros(max(n, 0), np.int32)
+        if n > 0:
+            self._chk(self.lib.mc_get_shared_indices(self.ctx, out.ctypes.data_as(C.POINTER(C.c_int))))
+        return out
+
+    def pack_shared(self, d_cx, d_buf, stream=None):
+        self._chk(self.lib.mc_pack_shared(self.ctx, C.c_void_p(d_cx), C.c_void_p(d_buf), C.c_void_p(stream or 0)))
+
+    def unpack_shared(self, d_buf, d_cx, stream=None):
+        self._chk(self.lib.mc_unpack_shared(self.ctx, C.c_void_p(d_buf), C.c_void_p(d_cx), C.c_void_p(stream or 0)))
+
     LAUNCH_NAMES = ("k_reproj", "k_group<StaticReproj>", "k_stream<Imu>", "k_stream<Lidar>", "k_motion")
 
     def launch_info(self):

@@ -134,6 +134,10 @@ struct Problem {
   //   oh[nob]      col_h of other block o
   //   ocolblk[G]   other block of each local other column
   std::vector<int> chunk_tab;
+  // Multi-GPU: value indices (into Cx) of the Hessian blocks that more than one rank's terms can write -- window
+  // halos of the coefficient band and the blocks between global design variables.  Only these need the all-reduce;
+  // every other entry is written by exactly one rank.  Empty for world == 1.
+  std::vector<int> shared_idx;
 
   // ------------------------------------------------------------------ description
   int addDv(int kind, const double* params, int n, int active, double scaling) {
@@ -677,6 +681,84 @@ inline void Problem::finalize() {
           b.max_terms = std::max(b.max_terms, c.term_count);
         }
     }
+  }
+  // ---- shared entries (world > 1): owner rank of every block pair over ALL ranks' work items
+  shared_idx.clear();
+  if (world > 1) {
+    std::vector<double> cutv;   // recover every rank's window: rank r owns [cutv[r], cutv[r+1])
+    {
+      // same cuts as above, recomputed for all ranks
+      struct GT { double t; double cost; };
+      std::vector<GT> all;
+      for (const Batch& b : batches) {
+        double per = b.kind == KIND_REPROJ ? 1.0 : (b.kind == KIND_LIDAR ? 1.5 : (b.kind == KIND_STATIC_REPROJ ? 1.0 : 4.0));
+        for (size_t g = 0; g < b.groups.size(); ++g) all.push_back(GT{b.group_time[g], 8.0 + per * b.groups[g].term_count});
+        for (size_t g = 0; g < b.chunks.size(); ++g) all.push_back(GT{b.chunk_time[g], 8.0 + per * b.chunks[g].term_count});
+      }
+      cutv.assign(world + 1, INFINITY);
+      cutv[0] = -INFINITY;
+      if (!all.empty()) {
+        std::sort(all.begin(), all.end(), [](const GT& a, const GT& b2) { return a.t < b2.t; });
+        double tot = 0;
+        for (auto& g : all) tot += g.cost;
+        double acc = 0;
+        int r = 1;
+        for (size_t i = 0; i < all.size() && r < world; ++i) {
+          acc += all[i].cost;
+          while (r < world && acc >= tot * r / world) { cutv[r] = (i + 1 < all.size()) ? 0.5 * (all[i].t + all[i + 1].t) : INFINITY; ++r; }
+        }
+      }
+    }
+    auto ownerOf = [&](double t) { int r = 0; while (r + 1 < world && t >= cutv[r + 1]) ++r; return r; };
+    std::vector<signed char> owner(pat_rows.size(), -1);   // -1 untouched, -2 shared, else rank
+    auto mark = [&](int b1, int b2, int r) {
+      int rb = std::min(b1, b2), cb = std::max(b1, b2);
+      const std::vector<int>& rows = col_rows[cb];
+      auto it = std::lower_bound(rows.begin(), rows.end(), rb);
+      if (it == rows.end() || *it != rb) return;
+      size_t k = pat_colptr[cb] + (it - rows.begin());
+      if (owner[k] == -1) owner[k] = (signed char)r;
+      else if (owner[k] != r) owner[k] = -2;
+    };
+    if (world > 120) throw std::invalid_argument("at most 120 shards");
+    for (const Batch& b : batches) {
+      for (size_t g = 0; g < b.groups.size(); ++g) {
+        int r = ownerOf(b.group_time[g]);
+        std::vector<int> blks;
+        for (auto& w : fp_written[b.groups[g].fp]) for (int k = 0; k < w[2]; ++k) blks.push_back(w[1] + k);
+        for (size_t i = 0; i < blks.size(); ++i) for (size_t j = i; j < blks.size(); ++j) mark(blks[i], blks[j], r);
+      }
+      const int pose_block0 = (b.spline >= 0 && !b.chunks.empty()) ? dvs[splines[b.spline].first_dv].block : -1;
+      for (size_t g = 0; g < b.chunks.size(); ++g) {
+        int r = ownerOf(b.chunk_time[g]);
+        const ChunkRec& c = b.chunks[g];
+        const int* of = &ofp_data[ofp_off[c.ofp]];
+        const int nob = of[0];
+        const int* ob = of + OFP_HDR;
+        for (int bj = 0; bj < c.pose_nb; ++bj) {
+          for (int d = 0; d < 6 && bj - d >= 0; ++d) mark(pose_block0 + c.pose_lo + bj - d, pose_block0 + c.pose_lo + bj, r);
+          for (int o = 0; o < nob; ++o) mark(ob[4 * o], pose_block0 + c.pose_lo + bj, r);
+        }
+        for (int o1 = 0; o1 < nob; ++o1) for (int o2 = o1; o2 < nob; ++o2) mark(ob[4 * o1], ob[4 * o2], r);
+      }
+      if (b.kind == KIND_MOTION) {
+        const SplineRec& sp = splines[b.spline];
+        int b0 = dvs[sp.first_dv].block;
+        if (b0 >= 0)
+          for (int i = 0; i < sp.n_coeff; ++i) for (int d = 0; d < sp.order && i - d >= 0; ++d) mark(b0 + i - d, b0 + i, 0);
+      }
+    }
+    for (int cb = 0; cb < n_blocks; ++cb)
+      for (int k = pat_colptr[cb]; k < pat_colptr[cb + 1]; ++k) {
+        if (owner[k] != -2) continue;
+        int rb = pat_rows[k], h = col_h[cb];
+        for (int sc = 0; sc < block_dim[cb]; ++sc) {
+          int base = pat_cp0[cb] + sc * h + (sc * (sc + 1)) / 2 + pat_roff[k];
+          int n = (rb == cb) ? sc + 1 : block_dim[rb];
+          for (int rr = 0; rr < n; ++rr) shared_idx.push_back(base + rr);
+        }
+      }
+    std::sort(shared_idx.begin(), shared_idx.end());
   }
   update_dvs = block_dv;
   finalized = true;

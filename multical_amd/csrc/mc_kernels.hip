@@ -148,7 +148,7 @@ __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, c
 }
 
 template <bool BUILD>
-__global__ __launch_bounds__(256) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
+__global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
                                                 const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
                                                 const F1Common* __restrict__ common, int jpart_base) {
   // One 256-thread workgroup per IMAGE; its observations (one per visible board) are processed one after the other.
@@ -709,6 +709,16 @@ __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ part, in
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+// multi-GPU combination: gather / scatter of the value entries that more than one rank writes
+__global__ __launch_bounds__(256) void k_pack(const int* __restrict__ idx, int n, const double* __restrict__ src, double* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ __launch_bounds__(256) void k_unpack(const int* __restrict__ idx, int n, const double* __restrict__ src, double* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[idx[i]] = src[i];
+}
+
 // Optimizer2::applyStateUpdate (Optimizer2.cpp:292-309) + every DesignVariable::updateImplementation
 struct UpdRec { int kind, dim, off, col; double scaling; };
 __global__ __launch_bounds__(256) void k_update(const UpdRec* __restrict__ recs, int n, const double* __restrict__ dx, double* x) {
@@ -791,7 +801,7 @@ struct mc_context {
   std::string err;
   int device = 0;
   DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, Jpart2, J, dx;
-  DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab;
+  DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab, shared_idx;
   DevBuf<UpdRec> upd;
   std::vector<std::unique_ptr<DevBatch>> db;
   LaunchUnit lu[N_LAUNCH];
@@ -852,6 +862,7 @@ void mc_context::uploadStructure() {
   ofp_data.upload(P.ofp_data); ofp_off.upload(P.ofp_off);
   pat_colptr.upload(P.pat_colptr); pat_rows.upload(P.pat_rows); pat_roff.upload(P.pat_roff); pat_cp0.upload(P.pat_cp0);
   chunk_tab.upload(P.chunk_tab);
+  shared_idx.upload(P.shared_idx);
   status.alloc(1);
   Cx.alloc(P.nnz); rhs.alloc(P.j_cols); e.alloc(P.j_rows); chi2.alloc(P.n_terms); J.alloc(1); dx.alloc(P.j_cols);
   std::vector<UpdRec> ur;
@@ -1250,6 +1261,32 @@ int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double*
   HIP_CHECK(hipStreamSynchronize(0));
   if (Cx_out) HIP_CHECK(hipMemcpy(Cx_out, ctx->Cx.p, sizeof(double) * ctx->P.nnz, hipMemcpyDeviceToHost));
   if (rhs_out) HIP_CHECK(hipMemcpy(rhs_out, ctx->rhs.p, sizeof(double) * ctx->P.j_cols, hipMemcpyDeviceToHost));
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_shared_count(const mc_context* ctx) { return ctx->P.finalized ? (int)ctx->P.shared_idx.size() : -1; }
+int mc_get_shared_indices(const mc_context* ctx, int* out) {
+  if (!ctx->P.finalized) return -1;
+  std::memcpy(out, ctx->P.shared_idx.data(), sizeof(int) * ctx->P.shared_idx.size());
+  return 0;
+}
+int mc_pack_shared(mc_context* ctx, const double* d_Cx, double* d_buf, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  int n = (int)ctx->P.shared_idx.size();
+  if (n == 0) return 0;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->shared_idx.p, n, d_Cx, d_buf);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_unpack_shared(mc_context* ctx, const double* d_buf, double* d_Cx, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  int n = (int)ctx->P.shared_idx.size();
+  if (n == 0) return 0;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->shared_idx.p, n, d_buf, d_Cx);
+  HIP_CHECK(hipGetLastError());
   return 0;
   MC_CATCH(ctx, -1)
 }

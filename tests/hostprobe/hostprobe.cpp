@@ -97,6 +97,12 @@ int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {
   }
   return 0;
 }
+int probe_shared_count(void* h) { return (int)((Probe*)h)->P.shared_idx.size(); }
+int probe_shared_indices(void* h, int* out) {
+  Problem& P = ((Probe*)h)->P;
+  std::memcpy(out, P.shared_idx.data(), sizeof(int) * P.shared_idx.size());
+  return 0;
+}
 // per-term flag: 1 if the term belongs to this rank's groups
 int probe_my_terms(void* h, int* flags) {
   Problem& P = ((Probe*)h)->P;

@@ -116,6 +116,13 @@ class ProbeApi(object):
     def term_kind(self, t):
         return self.L.probe_term_kind(self.h, C.c_int(t))
 
+    def shared_indices(self):
+        n = self.L.probe_shared_count(self.h)
+        out = np.zeros(n, np.int32)
+        if n:
+            self.L.probe_shared_indices(self.h, _i(out))
+        return out
+
     def my_terms(self):
         f = np.zeros(self.n_terms, np.int32)
         self.L.probe_my_terms(self.h, _i(f))

@@ -145,6 +145,40 @@ def test_two_shards_sum_to_the_whole(small_problem, hip_small):
     _close(es, e, 1e-15)
 
 
+def test_shared_entries_are_all_that_needs_reducing(small_problem, hip_small):
+    """bench.py's N > 1 combination on one GPU: three shard contexts, pack -> sum of the compact buffers (what the RCCL
+    all-reduce does) -> unpack; outside the shared set every entry is written by at most one rank, and owner values +
+    reduced shared values reproduce the unsharded system."""
+    import torch
+    g, _ = hip_small
+    Cx, rhs = g.build_system(True)
+    world = 3
+    parts = [_hip(small_problem["spec"], r, world)[0] for r in range(world)]
+    sidx = parts[0].shared_indices()
+    assert all(np.array_equal(sidx, p.shared_indices()) for p in parts)
+    assert 0 < sidx.size < 0.6 * g.nnz
+    st = torch.cuda.current_stream().cuda_stream
+    d = [torch.zeros(g.nnz, dtype=torch.float64, device="cuda:0") for _ in parts]
+    drhs = torch.zeros(g.j_cols, dtype=torch.float64, device="cuda:0")
+    bufs = [torch.zeros(sidx.size, dtype=torch.float64, device="cuda:0") for _ in parts]
+    for p, dc, b in zip(parts, d, bufs):
+        p.build_system_device(True, dc.data_ptr(), drhs.data_ptr(), st)
+        p.pack_shared(dc.data_ptr(), b.data_ptr(), st)
+    total = sum(bufs)                       # the all-reduce
+    for p, dc in zip(parts, d):
+        p.unpack_shared(total.data_ptr(), dc.data_ptr(), st)
+    torch.cuda.synchronize()
+    h = [x.cpu().numpy() for x in d]
+    private = np.ones(g.nnz, bool)
+    private[sidx] = False
+    writers = sum(((x != 0.0) & private).astype(int) for x in h)
+    assert writers.max() <= 1
+    whole = np.where(private, sum(np.where(private, x, 0.0) for x in h), h[0])
+    _close(whole, Cx, 1e-12)
+    for x in h[1:]:
+        assert np.array_equal(x[sidx], h[0][sidx])
+
+
 def test_device_pointer_entry_points(hip_small):
     import torch
     g, _ = hip_small

@@ -51,14 +51,28 @@ def _worker(rank, world, port, out_path):
         rhs -= Jt.T @ e
     # values in the global CCS order (upper triangle)
     cols = np.repeat(np.arange(n), np.diff(Cp))
-    Cx = torch.from_numpy(Hd[Ci, cols].copy())
+    Cx_local = Hd[Ci, cols].copy()
+    # bench.py's combination: only the entries more than one rank can write go through the all-reduce
+    sidx = p.shared_indices().astype(np.int64)
+    buf = torch.from_numpy(Cx_local[sidx].copy())
+    dist.all_reduce(buf)
+    Cx_local[sidx] = buf.numpy()
+    # everything else must be owned by exactly one rank: count the ranks with a non-zero there
+    private = np.ones(Cx_local.size, bool)
+    private[sidx] = False
+    touched = torch.from_numpy(((Cx_local != 0.0) & private).astype(np.float64))
+    dist.all_reduce(touched)
+    assert float(touched.max()) <= 1.0, "an entry outside the shared set is written by two ranks"
+    # assemble the whole matrix for the comparison: shared part from any rank, private part = sum (one owner each)
+    priv = torch.from_numpy(np.where(private, Cx_local, 0.0))
+    dist.all_reduce(priv)
+    Cx = torch.from_numpy(np.where(private, priv.numpy(), Cx_local))
     rhs_t = torch.from_numpy(rhs)
     cnt = torch.tensor([float(mine.sum())], dtype=torch.float64)
-    dist.all_reduce(Cx)
     dist.all_reduce(rhs_t)
     dist.all_reduce(cnt)
     if rank == 0:
-        np.savez(out_path, Cx=Cx.numpy(), rhs=rhs_t.numpy(), count=cnt.numpy(), kinds=np.array([p.term_kind(t) for t in range(p.n_terms)]),
+        np.savez(out_path, Cx=Cx.numpy(), rhs=rhs_t.numpy(), count=cnt.numpy(), n_shared=sidx.size, nnz=Cx_local.size, kinds=np.array([p.term_kind(t) for t in range(p.n_terms)]),
                  n_terms=p.n_terms)
     dist.barrier()
     dist.destroy_process_group()
@@ -72,6 +86,7 @@ def test_two_rank_partial_systems_sum_to_the_oracle(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = np.load(out)
     assert int(got["count"][0]) == int(got["n_terms"])          # every term owned by exactly one rank
+    assert 0 < int(got["n_shared"]) < 0.5 * int(got["nnz"])     # the all-reduce moves a fraction of the matrix
     cfg = synth.SynthConfig(duration=1.0, n_cams=2, n_imus=1, n_lidars=1, lidar_points_per_frame=10, corner_stride=16,
                             huber_accel=1.0, blake_zisserman_cam=2, bias_motion_terms=False)
     spec, H, W, meas = synth.make_problem(cfg, OracleApi)
