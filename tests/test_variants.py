@@ -1,0 +1,166 @@
+"""Edge cases of the problem description, each checked three ways: bit-exact pattern, the product's closed forms on the
+host (tests/hostprobe) against the oracle term by term, and -- on the GPU -- evaluateError / buildSystem through the C
+ABI against the oracle (1e-9).  Variants of the small Multical problem:
+  no_time_calibration   time-offset design variables inactive (front-end flag --no-time-calibration)
+  pose_fixed            pose spline inactive: only extrinsics / biases are estimated
+  static_bias_point_g   IMU biases as static EuclideanPoint design variables, gravity as EuclideanPoint
+                        (kalibr's estimateGravityLength path) instead of bias splines / EuclideanDirection
+  all_mestimators       Cauchy, Geman-McClure, Huber and "bz" spread over the batches
+  unsorted_streams      LiDAR and IMU samples handed over in shuffled time order
+  ragged                observations cut down to 1..3 corners, one LiDAR batch emptied to a single point
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from multical_amd import spec as S
+
+RTOL = 1e-9
+VARIANTS = ["no_time_calibration", "pose_fixed", "static_bias_point_g", "all_mestimators", "unsorted_streams", "ragged"]
+
+
+def make_variant(spec, name):
+    sp = copy.deepcopy(spec)
+    rng = np.random.default_rng(11)
+    if name == "no_time_calibration":
+        for k, d in sp.ops:
+            if k == "dv" and d["kind"] == S.DV_SCALAR:
+                d["active"] = False
+    elif name == "pose_fixed":
+        for k, d in sp.ops:
+            if k == "spline" and d["dim"] == 6:
+                d["active"] = False
+    elif name == "static_bias_point_g":
+        for k, d in sp.ops:
+            if k == "dv" and d["kind"] == S.DV_EUCLIDEAN_DIRECTION:
+                d["kind"] = S.DV_EUCLIDEAN_POINT      # same 3-vector, now 3 degrees of freedom
+        for i, k, d in sp.batch_ops():
+            if k in ("accel", "gyro"):
+                b = sp.add_dv(S.DV_EUCLIDEAN_POINT, 0.01 * rng.standard_normal(3), True, 1.0, S.HELPER_GROUP_ID)
+                d["bias_spline"], d["dv_bias"] = -1, b
+        assert not any(k == "motion" for k, d in sp.ops)   # the fixture removes them (their splines have no terms left)
+    elif name == "all_mestimators":
+        kinds = [(S.MEST_CAUCHY, 3.0), (S.MEST_GEMAN_MCCLURE, 2.0), (S.MEST_HUBER, 0.7), (S.MEST_BZ, 1.5), (S.MEST_NONE, 0.0)]
+        n = 0
+        for i, k, d in sp.batch_ops():
+            if k != "motion":
+                d["mest"], d["mest_param"] = kinds[n % len(kinds)]
+                n += 1
+    elif name == "unsorted_streams":
+        for i, k, d in sp.batch_ops():
+            if k == "lidar":
+                p = rng.permutation(d["t"].size)
+                for f in ("t", "dir", "range", "sinv"):
+                    d[f] = d[f][p]
+                d["dv_q_pw"] = [d["dv_q_pw"][j] for j in p]
+                d["dv_t_pw"] = [d["dv_t_pw"][j] for j in p]
+            elif k in ("accel", "gyro"):
+                p = rng.permutation(d["t"].size)
+                for f in ("t", "meas", "sinv"):
+                    d[f] = d[f][p]
+    elif name == "ragged":
+        for i, k, d in sp.batch_ops():
+            if k == "reproj":
+                first = d["obs_first"]
+                keep, nf = [], [0]
+                for o in range(first.size - 1):
+                    m = min(int(first[o + 1] - first[o]), 1 + o % 3)
+                    keep += list(range(first[o], first[o] + m))
+                    nf.append(nf[-1] + m)
+                for f in ("y", "p", "sinv"):
+                    d[f] = d[f][keep]
+                d["obs_first"] = np.array(nf, np.int32)
+        lid = [d for _, k, d in sp.batch_ops() if k == "lidar"]
+        if lid:
+            d = lid[0]
+            for f in ("t", "dir", "range", "sinv"):
+                d[f] = d[f][:1]
+            d["dv_q_pw"], d["dv_t_pw"] = d["dv_q_pw"][:1], d["dv_t_pw"][:1]
+    else:
+        raise KeyError(name)
+    return sp
+
+
+@pytest.fixture(scope="module")
+def variants(small_problem):
+    from oracle_api import OracleApi
+    out = {}
+    for name in VARIANTS:
+        base = small_problem["spec"]
+        if name == "static_bias_point_g":
+            # drop the motion ops first (on a copy) so that op indices -- which are the handles -- stay valid
+            base = copy.deepcopy(base)
+            idx_map, ops = {}, []
+            for i, (k, d) in enumerate(base.ops):
+                if k != "motion":
+                    idx_map[i] = len(ops)
+                    ops.append((k, d))
+            def rm(h):
+                return h if (h is None or h < 0) else idx_map[h]
+            for k, d in ops:
+                for f, v in list(d.items()):
+                    if f in ("camera", "spline", "pose_spline", "bias_spline", "dv_proj", "dv_dist") or f.startswith("dv_") and not isinstance(v, list):
+                        if isinstance(v, (int, np.integer)):
+                            d[f] = rm(int(v))
+                    elif isinstance(v, list) and (f.startswith("obs_dv") or f.startswith("dv_") or f.startswith("chain_dv")):
+                        d[f] = [rm(h) for h in v]
+            base.ops = ops
+        sp = make_variant(base, name)
+        o = OracleApi()
+        sp.emit(o)
+        o.finalize()
+        out[name] = (sp, o)
+    return out
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_variant_product_math_matches_oracle(variants, name):
+    from probe_api import ProbeApi
+    sp, o = variants[name]
+    p = ProbeApi()
+    sp.emit(p)
+    p.finalize()
+    assert (p.j_rows, p.j_cols, p.n_blocks, p.n_terms) == (o.j_rows, o.j_cols, o.n_blocks, o.n_terms)
+    o.evaluate_error(True)
+    Cp, Ci, _, _ = o.build_system(True)
+    Cp2, Ci2 = p.pattern()
+    assert np.array_equal(Cp, Cp2) and np.array_equal(Ci, Ci2)
+    chi = o.term_chi2()
+    wj = we = wc = 0.0
+    step = max(1, o.n_terms // 400)
+    for t in range(0, o.n_terms, step):
+        if p.term_kind(t) == 5:
+            continue
+        Ja, ea = o.term_weighted_jacobian(t, True)
+        Jp, ep, c = p.term(t, True)
+        wj = max(wj, np.abs(Ja - Jp).max() / max(1e-300, np.abs(Ja).max()))
+        we = max(we, np.abs(ea - ep).max() / max(1e-9, np.abs(ea).max()))
+        wc = max(wc, abs(c - chi[t]) / max(1e-9, chi[t]))
+    assert wj < RTOL and we < RTOL and wc < RTOL, (wj, we, wc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", VARIANTS)
+def test_variant_gpu_parity(variants, name):
+    from multical_amd.backend import HipApi
+    sp, o = variants[name]
+    g = HipApi(0)
+    sp.emit(g)
+    g.finalize()
+    for use_mest in (True, False):
+        Jo, eo = o.evaluate_error(use_mest)
+        Cp, Ci, Cx, rhs = o.build_system(use_mest)
+        Cpg, Cig = g.pattern()
+        assert np.array_equal(Cp, Cpg) and np.array_equal(Ci, Cig)
+        Jg, eg = g.evaluate_error(use_mest)
+        assert abs(Jg - Jo) <= RTOL * abs(Jo)
+        assert np.abs(eg - eo).max() <= RTOL * np.abs(eo).max()
+        cg, co = g.term_chi2(), o.term_chi2()
+        assert np.abs(cg - co).max() <= RTOL * np.abs(co).max()
+        Cxg, rhsg = g.build_system(use_mest)
+        assert np.abs(Cxg - Cx).max() <= RTOL * np.abs(Cx).max()
+        assert np.linalg.norm(Cxg - Cx) <= RTOL * np.linalg.norm(Cx)
+        assert np.abs(rhsg - rhs).max() <= RTOL * np.abs(rhs).max()
+        assert np.all(Cxg[Cx == 0.0] == 0.0)
+    g.check_status()
