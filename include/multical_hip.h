@@ -168,6 +168,9 @@ int mc_num_launches(const mc_context* ctx);
 int mc_launch_info(const mc_context* ctx, int launch, int* n_batches, int* n_terms, int* n_workgroups);
 int mc_launch_counts(const mc_context* ctx, int launch, double* flops_dense, double* flops_live, double* record_bytes);
 int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float* ms_per_launch);
+/* In-kernel phase timing: one pass with a shader-clock mark after every phase of k_reproj (slots 0..6) and k_stream
+ * (lidar 8..12, IMU 16..20), summed over workgroups (wave 0 of each).  out24: 24 cycle sums. */
+int mc_phase_cycles(mc_context* ctx, int use_mestimator, int build, unsigned long long* out24);
 
 /* number of multiprocessors etc. for reports; returns 0 and fills what it can */
 int mc_device_info(mc_context* ctx, char* name, int name_len, int* n_cu, double* hbm_gib);

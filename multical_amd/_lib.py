@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmulticalhip.so")
+# MULTICAL_HIP_LIB selects another build of the same library (e.g. the phase-timing diagnostic build)
+LIB_PATH = os.environ.get("MULTICAL_HIP_LIB") or os.path.join(_HERE, "libmulticalhip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -54,6 +55,7 @@ SIGNATURES = {
     "mc_num_launches": (C.c_int, [_ctx]),
     "mc_launch_info": (C.c_int, [_ctx, C.c_int, _ip, _ip, _ip]),
     "mc_launch_counts": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
+    "mc_phase_cycles": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
     "mc_build_system_timed": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mc_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, _ip, _dp]),
 }

@@ -219,6 +219,11 @@ class HipApi(object):
         self._chk(self.lib.mc_build_system_timed(self.ctx, int(use_mest), int(build), ms.ctypes.data_as(C.POINTER(C.c_float))))
         return ms
 
+    def phase_cycles(self, use_mest=True, build=1):
+        out = (C.c_ulonglong * 24)()
+        self._chk(self.lib.mc_phase_cycles(self.ctx, int(use_mest), int(build), out))
+        return np.array(list(out), dtype=np.float64)
+
     def device_info(self):
         name = C.create_string_buffer(256)
         ncu, gib = C.c_int(), C.c_double()

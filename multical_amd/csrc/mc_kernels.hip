@@ -45,7 +45,24 @@ struct DevCommon {
   int* status;
   int useM;
   int build;
+  unsigned long long* phase;   // optional (mc_phase_cycles): per-phase cycle sums written by wave 0 of each workgroup
 };
+// phase timing marks: compiled in only with -DMC_PHASE_TIMING (a separate diagnostic build, scripts/build_timing_lib.sh):
+// even a disabled mark costs registers in kernels that already sit at the occupancy limit
+#ifdef MC_PHASE_TIMING
+#define MC_MARK(slot)                                                                      \
+  do {                                                                                     \
+    if (dc.phase && threadIdx.x == 0) {                                                    \
+      unsigned long long _t = clock64();                                              \
+      atomicAdd(dc.phase + (slot), _t - _tmark);                                           \
+      _tmark = _t;                                                                         \
+    }                                                                                      \
+  } while (0)
+#define MC_MARK_BEGIN() unsigned long long _tmark = (dc.phase && threadIdx.x == 0) ? clock64() : 0ull
+#else
+#define MC_MARK(slot) do { } while (0)
+#define MC_MARK_BEGIN() do { } while (0)
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -108,40 +125,45 @@ enum { F1_LD = F1_CORE + 2, F1_ROWS = 256 };  // 21: odd stride, conflict-free c
 // consecutive observations (groups) of one camera taken at the same time: one image seeing several boards
 struct ImageRec { int first, count; };
 
-// Expansion of a 20 x 20 core Gram (Msh, upper triangle, idx = b(b+1)/2 + a; column 19 = residual) to Hessian entries:
-// core columns 0..5 fan out to the 6 live coefficient blocks with the basis weights, the others map 1:1.
-// board_part selects the pairs that involve a board-pose column (core 12..17) or those that do not.
+// Expansion of a 20 x 20 core Gram (Msh, upper triangle, idx = b(b+1)/2 + a; column 19 = residual) to Hessian entries.
+// "Live" columns: 0..ncoef-1 are the 6 live coefficient blocks (core columns 0..5 fanned out with the basis weights),
+// then the global columns glc[] / core columns gk[], ordered so that the n_nb columns that do NOT belong to the board
+// pose come first.  board_part = false: all pairs among the first M = ncoef + n_nb live columns (once per image);
+// board_part = true: every pair with a board column (once per observation).
+__device__ __forceinline__ void f1_live(int p, int ncoef, int rc0, int coef_shift, const double* w, const int* glc, const int* gk,
+                                        int& lc, int& k, double& wt) {
+  if (p < ncoef) { int i = p / 6; k = p - 6 * i; lc = rc0 + 6 * (coef_shift + i) + k; wt = w[i]; }
+  else { lc = glc[p - ncoef]; k = gk[p - ncoef]; wt = 1.0; }
+}
 __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, const double* Msh, const double* w, int rc0,
-                                         int coef_shift, const int* glc, const int* gk, int nglob, bool board_part, int tid) {
+                                         int coef_shift, const int* glc, const int* gk, int n_nb, int nglob, bool board_part, int tid) {
   const int ncoef = rc0 >= 0 ? 36 : 0;
-  const int nlive = ncoef + nglob;
-  const int npair = nlive * (nlive + 1) / 2;
+  const int nlive = ncoef + nglob, M = ncoef + n_nb;
+  const int npair = board_part ? (nlive - M) * nlive : M * (M + 1) / 2;
   for (int idx = tid; idx < npair; idx += 256) {
-    int q = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
-    while ((q + 1) * (q + 2) / 2 <= idx) ++q;
-    while (q * (q + 1) / 2 > idx) --q;
-    int p = idx - q * (q + 1) / 2;
+    int p, q;
+    if (board_part) { q = M + idx / nlive; p = idx - (q - M) * nlive; if (p > q) continue; }
+    else {
+      q = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+      while ((q + 1) * (q + 2) / 2 <= idx) ++q;
+      while (q * (q + 1) / 2 > idx) --q;
+      p = idx - q * (q + 1) / 2;
+    }
     int lcp, kp_, lcq, kq_;
     double wp, wq;
-    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = w[i]; }
-    else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
-    if (q < ncoef) { int i = q / 6; kq_ = q - 6 * i; lcq = rc0 + 6 * (coef_shift + i) + kq_; wq = w[i]; }
-    else { lcq = glc[q - ncoef]; kq_ = gk[q - ncoef]; wq = 1.0; }
-    const bool brd = (kp_ >= 12 && kp_ <= 17) || (kq_ >= 12 && kq_ <= 17);
-    if (brd != board_part) continue;
+    f1_live(p, ncoef, rc0, coef_shift, w, glc, gk, lcp, kp_, wp);
+    f1_live(q, ncoef, rc0, coef_shift, w, glc, gk, lcq, kq_, wq);
     int ka = min(kp_, kq_), kb = max(kp_, kq_);
     double v = wp * wq * Msh[kb * (kb + 1) / 2 + ka];
     int ca = min(lcp, lcq), cb = max(lcp, lcq);
     int addr = entry_addr(f, dc.col_h, ca, cb);
     if (dc.build == 1 || v == 1.2345e-300) atomic_add_f64(dc.Cx + addr, v);
   }
-  for (int p = tid; p < nlive; p += 256) {
+  const int p0 = board_part ? M : 0, p1 = board_part ? nlive : M;
+  for (int p = p0 + tid; p < p1; p += 256) {
     int lcp, kp_;
     double wp;
-    if (p < ncoef) { int i = p / 6; kp_ = p - 6 * i; lcp = rc0 + 6 * (coef_shift + i) + kp_; wp = w[i]; }
-    else { lcp = glc[p - ncoef]; kp_ = gk[p - ncoef]; wp = 1.0; }
-    const bool brd = kp_ >= 12 && kp_ <= 17;
-    if (brd != board_part) continue;
+    f1_live(p, ncoef, rc0, coef_shift, w, glc, gk, lcp, kp_, wp);
     double v = -wp * Msh[19 * 20 / 2 + kp_];
     if (dc.build == 1 || v == 1.2345e-300) atomic_add_f64(dc.rhs + global_col(f, lcp), v);
   }
@@ -159,7 +181,6 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
   __shared__ double rows[F1_ROWS * F1_LD];
   __shared__ double Msh[210];
   __shared__ int glc[13], gk[13];
-  __shared__ int nglob;
   __shared__ double red[4];
   // the per-observation quantities (k_obs_common) are uniform over the workgroup: parked in LDS and read back by
   // broadcast so they do not occupy ~110 vector registers per lane
@@ -182,28 +203,50 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
   }
   const bool my_board_entry = (ea >= 12 && ea <= 17) || (eb >= 12 && eb <= 17);
   bool any_done = false;
-  int last_rc0 = -1, last_shift = 0;
+  int last_rc0 = -1, last_shift = 0, last_nnb = 0;
   bool last_staged = false;
   int last_fp_begin = 0;
   // build: two threads per corner (one residual row each); evaluate only: one thread per corner
   constexpr int CPP = BUILD ? F1_ROWS / 2 : F1_ROWS;   // corners per pass
   const int r = BUILD ? (tid & 1) : 0;
+  // The per-observation record and footprint of observation go + 1 are fetched into registers while observation go is
+  // being processed (the barriers below only wait for LDS, so the loads stay in flight across them).
+  static_assert(sizeof(F1Common) % 8 == 0 && sizeof(F1Common) / 8 <= 256, "F1Common is copied as doubles, one per thread");
+  double pf_cm = 0.0;
+  int pf_fp[FP_LDS / 256] = {0, 0, 0};
+  GroupRec gr_next = groups[im.first];
+  int fpb_next = dc.fp_off[gr_next.fp], fpl_next = dc.fp_off[gr_next.fp + 1] - fpb_next;
+  auto prefetch = [&](int gi, int fp_begin, int fp_len) {
+    if (tid < (int)(sizeof(F1Common) / 8)) pf_cm = reinterpret_cast<const double*>(common + gi)[tid];
+    if (BUILD && fp_len <= FP_LDS) {
+#pragma unroll
+      for (int j = 0; j < FP_LDS / 256; ++j) if (tid + 256 * j < fp_len) pf_fp[j] = dc.fp_data[fp_begin + tid + 256 * j];
+    }
+  };
+  prefetch(im.first, fpb_next, fpl_next);
+  MC_MARK_BEGIN();
   for (int go = 0; go < im.count; ++go) {
     const int gi = im.first + go;
     any_done = false;   // the image-level flush below needs the LAST observation's tables intact
-    const GroupRec gr = groups[gi];
+    const GroupRec gr = gr_next;
     const ReprojBatchView b = views[gr.batch];
-    const int fp_begin = dc.fp_off[gr.fp], fp_len = dc.fp_off[gr.fp + 1] - fp_begin;
+    const int fp_begin = fpb_next, fp_len = fpl_next;
     const bool fp_staged = BUILD && fp_len <= FP_LDS;
     __syncthreads();   // previous observation's flush is done with cm / fpl / Msh
     {
-      static_assert(sizeof(F1Common) % 8 == 0, "F1Common is copied as doubles");
-      const double* src = reinterpret_cast<const double*>(common + gi);
-      double* dst = reinterpret_cast<double*>(&cm);
-      if (tid < (int)(sizeof(F1Common) / 8)) dst[tid] = src[tid];
-      if (fp_staged) for (int i = tid; i < fp_len; i += 256) fpl[i] = dc.fp_data[fp_begin + i];
+      if (tid < (int)(sizeof(F1Common) / 8)) reinterpret_cast<double*>(&cm)[tid] = pf_cm;
+      if (fp_staged) {
+#pragma unroll
+        for (int j = 0; j < FP_LDS / 256; ++j) if (tid + 256 * j < fp_len) fpl[tid + 256 * j] = pf_fp[j];
+      }
     }
     __syncthreads();
+    MC_MARK(0);   // record + footprint staged
+    if (go + 1 < im.count) {
+      gr_next = groups[gi + 1];
+      fpb_next = dc.fp_off[gr_next.fp]; fpl_next = dc.fp_off[gr_next.fp + 1] - fpb_next;
+      prefetch(gi + 1, fpb_next, fpl_next);
+    }
     if (!cm.ok) { if (tid == 0) atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); continue; }
     FpView f = fp_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + fp_begin);
     const int rc0 = f.rolecol[F1_ROLE_COEF];
@@ -212,6 +255,26 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
       // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
       coef_shift = cm.seg - f.coef_lo;
       if (coef_shift < 0 || coef_shift + S6 > f.nbuf) { if (tid == 0) atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); continue; }
+    }
+    // global live columns, non-board first: q_c_b (core 6..8), t_c_b (9..11), time offset (18), then q_p_w (12..14),
+    // t_p_w (15..17); thread t < 13 places one column (the later barriers publish glc / gk)
+    int n_nb = 0, n_glob = 0;
+    if (BUILD) {
+      const int a_qcb = f.rolecol[F1_ROLE_QCB] >= 0, a_tcb = f.rolecol[F1_ROLE_TCB] >= 0, a_toff = f.rolecol[F1_ROLE_TOFF] >= 0;
+      const int a_qpw = f.rolecol[F1_ROLE_QPW] >= 0, a_tpw = f.rolecol[F1_ROLE_TPW] >= 0;
+      n_nb = 3 * a_qcb + 3 * a_tcb + a_toff;
+      n_glob = n_nb + 3 * a_qpw + 3 * a_tpw;
+      if (tid < 13) {
+        // slot order: [qcb 0..2][tcb 3..5][toff 6][qpw 7..9][tpw 10..12]
+        int role, d, pos, kcore;
+        if (tid < 3) { role = F1_ROLE_QCB; d = tid; pos = 0; kcore = 6 + d; }
+        else if (tid < 6) { role = F1_ROLE_TCB; d = tid - 3; pos = 3 * a_qcb; kcore = 9 + d; }
+        else if (tid == 6) { role = F1_ROLE_TOFF; d = 0; pos = 3 * a_qcb + 3 * a_tcb; kcore = 18; }
+        else if (tid < 10) { role = F1_ROLE_QPW; d = tid - 7; pos = n_nb; kcore = 12 + d; }
+        else { role = F1_ROLE_TPW; d = tid - 10; pos = n_nb + 3 * a_qpw; kcore = 15 + d; }
+        const int rc = f.rolecol[role];
+        if (rc >= 0) { glc[pos + d] = rc + d; gk[pos + d] = kcore; }
+      }
     }
     f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0};
     for (int base = 0; base < gr.term_count; base += CPP) {
@@ -235,11 +298,13 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
           row[F1_CORE] = er;
         }
       }
+      MC_MARK(1);   // projection + chain rows
       if (BUILD) {
         // 20 x 20 core Gram R^T R on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A[i][k] = R[k][i] and
         // B[k][j] = R[k][j] one double per lane (lane = 16 (k % 4) + column), so a K-step of 4 rows costs two LDS
         // reads and three MFMAs (column tiles 0..15 and 16..19: blocks 00, 01, 11).  The 4 waves take every 4th K-step.
         __syncthreads();
+        MC_MARK(2); // waiting for the other waves' rows
         const int lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
         const int nsteps = (nrows + 3) >> 2;
         for (int st = tid >> 6; st < nsteps; st += 4) {
@@ -251,6 +316,7 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
           acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc11, 0, 0, 0);
         }
         __syncthreads();
+        MC_MARK(3); // MFMA Gram
       }
     }
     if (BUILD) {
@@ -264,13 +330,6 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
         stage[((wv * 3 + 1) * 4 + rg) * 64 + lane] = acc01[rg];
         stage[((wv * 3 + 2) * 4 + rg) * 64 + lane] = acc11[rg];
       }
-      if (tid == 0) {
-        int n = 0;
-        for (int g = 0; g < 4; ++g)
-          if (f.rolecol[1 + g] >= 0) for (int d = 0; d < 3; ++d) { glc[n] = f.rolecol[1 + g] + d; gk[n] = 6 + 3 * g + d; ++n; }
-        if (f.rolecol[F1_ROLE_TOFF] >= 0) { glc[n] = f.rolecol[F1_ROLE_TOFF]; gk[n] = 18; ++n; }
-        nglob = n;
-      }
       __syncthreads();
       if (tid < 210) {
         const int t = ea >= 16 ? 2 : (eb >= 16 ? 1 : 0);
@@ -281,8 +340,11 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
         if (!my_board_entry) img_acc += m;
       }
       __syncthreads();
+      MC_MARK(4);   // tiles -> Msh
       // board rows / columns of this observation
-      if (dc.build != 3) f1_flush(f, dc, Msh, cm.w, rc0, coef_shift, glc, gk, nglob, true, tid);
+      if (dc.build != 3) f1_flush(f, dc, Msh, cm.w, rc0, coef_shift, glc, gk, n_nb, n_glob, true, tid);
+      last_nnb = n_nb;
+      MC_MARK(5);   // board flush
       any_done = true; last_rc0 = rc0; last_shift = coef_shift; last_staged = fp_staged; last_fp_begin = fp_begin;
     }
   }
@@ -296,7 +358,8 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
   if (tid < 210) Msh[tid] = img_acc;
   __syncthreads();
   FpView f = last_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + last_fp_begin);
-  f1_flush(f, dc, Msh, cm.w, last_rc0, last_shift, glc, gk, nglob, false, tid);
+  f1_flush(f, dc, Msh, cm.w, last_rc0, last_shift, glc, gk, last_nnb, last_nnb, false, tid);
+  MC_MARK(6);   // image flush
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,6 +491,8 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
     for (int i = tid; i < ch.tab_len; i += 256) tab[i] = dc.chunk_tab[ch.tab_off + i];
     __syncthreads();
   }
+  MC_MARK_BEGIN();
+  const int pslot = D == 1 ? 8 : 16;
   // ---- phase 1: one term per thread
   double Jacc = 0.0;
   if (tid < T) {
@@ -454,9 +519,11 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
       if (build) beta0[tid] = -1000;   // covers nothing
     }
   }
+  MC_MARK(pslot + 0);   // term evaluation (wave 0's terms)
   Jacc = wave_sum(Jacc);
   if ((tid & 63) == 0) red[tid >> 6] = Jacc;
   __syncthreads();
+  MC_MARK(pslot + 1);   // waiting for the other waves
   if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
   if (!build) return;
   // Terms are time sorted and share one time offset, so beta0 is non-decreasing over the chunk and the terms of
@@ -499,6 +566,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
     for (int cb = 0; cb < 6; ++cb)
       if (acc[cb] != 0.0 && !(d == 0 && ra > cb)) atomic_add_f64(dc.Cx + slot + cb * h + (cb * (cb + 1)) / 2 + ra, acc[cb]);
   }
+  MC_MARK(pslot + 2);   // band gather + flush
   // ---- phase 2 (ii): coefficient x other columns (and the coefficient part of rhs: other column G = residual).
   // One thread per (coefficient column, tile of GT other columns).
   constexpr int GT = 7;
@@ -536,6 +604,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
       else atomic_add_f64(dc.Cx + slot + sc * oh[o] + (sc * (sc + 1)) / 2 + ra, acc[j]);                          // column = other
     }
   }
+  MC_MARK(pslot + 3);   // coefficient x other gather + flush
   // ---- phase 2 (iii): other x other (upper triangle) and the other part of rhs
   const int G1 = G + 1;
   for (int idx = tid; idx < G1 * G1; idx += 256) {
@@ -562,6 +631,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
       if (slot >= 0) atomic_add_f64(dc.Cx + slot + s1 * oh[o1] + (s1 * (s1 + 1)) / 2 + s2, acc);
     }
   }
+  MC_MARK(pslot + 4);   // other x other
 }
 
 template <class View, bool BUILD>
@@ -803,6 +873,8 @@ struct mc_context {
   DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, Jpart2, J, dx;
   DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab, shared_idx;
   DevBuf<UpdRec> upd;
+  DevBuf<unsigned long long> phase;
+  bool phase_on = false;
   std::vector<std::unique_ptr<DevBatch>> db;
   LaunchUnit lu[N_LAUNCH];
   int n_jpart = 0;
@@ -1061,6 +1133,7 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   dc.chunk_tab = chunk_tab.p;
   dc.Cx = dCx; dc.rhs = dRhs; dc.e = dE; dc.chi2 = chi2.p; dc.Jpart = Jpart.p; dc.status = status.p;
   dc.useM = useM; dc.build = build;
+  dc.phase = phase_on ? phase.p : nullptr;
   if (build) {
     HIP_CHECK(hipMemsetAsync(dCx, 0, sizeof(double) * P.nnz, st));
     HIP_CHECK(hipMemsetAsync(dRhs, 0, sizeof(double) * P.j_cols, st));
@@ -1316,6 +1389,23 @@ int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float*
   HIP_CHECK(hipStreamSynchronize(0));
   for (int i = 0; i < N_LAUNCH; ++i) HIP_CHECK(hipEventElapsedTime(&ms_per_launch[i], ev[i], ev[i + 1]));
   for (auto& e : ev) (void)hipEventDestroy(e);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_phase_cycles(mc_context* ctx, int use_mestimator, int build, unsigned long long* out24) {
+  MC_TRY MC_NEED_FINAL(ctx);
+#ifndef MC_PHASE_TIMING
+  throw std::logic_error("this build has no phase marks; compile with -DMC_PHASE_TIMING (scripts/build_timing_lib.sh)");
+#endif
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!ctx->phase.p) ctx->phase.alloc(24);
+  HIP_CHECK(hipMemset(ctx->phase.p, 0, 24 * sizeof(unsigned long long)));
+  ctx->phase_on = true;
+  try { ctx->launchAll(build, use_mestimator, ctx->Cx.p, ctx->rhs.p, build ? nullptr : ctx->J.p, nullptr, 0); }
+  catch (...) { ctx->phase_on = false; throw; }
+  ctx->phase_on = false;
+  HIP_CHECK(hipStreamSynchronize(0));
+  HIP_CHECK(hipMemcpy(out24, ctx->phase.p, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
   MC_CATCH(ctx, -1)
 }

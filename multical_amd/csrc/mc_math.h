@@ -12,6 +12,13 @@
 #else
 #define MC_HD inline
 #endif
+// Scheduling fence for the device code: keeps the compiler from hoisting every operand load of a long straight-line
+// chain to its top (which costs ~2 VGPRs per hoisted double and, past the occupancy target, scratch spills).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MC_SCHED_FENCE() ((void)0)
+#endif
 
 namespace mc {
 

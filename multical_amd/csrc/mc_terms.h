@@ -119,6 +119,8 @@ struct F1Common {
   double r[3], S[9];   // body position and S(theta) at t + d
   double cd[6];        // time derivative of the spline value
   double w[S6];        // basis weights of the 6 live coefficients
+  double pp[6], dk[4]; // projection / distortion parameters of the camera (copied here so that the corner loop reads
+                       // them from the staged record instead of issuing dependent global loads)
   int seg, ok;
 };
 MC_HD void f1_common(const ReprojBatchView& b, const double* x, int obs, F1Common& cm) {
@@ -126,6 +128,10 @@ MC_HD void f1_common(const ReprojBatchView& b, const double* x, int obs, F1Commo
   PoseSample ps;
   cm.ok = pose_sample<2>(b.sp, x, t, ps) ? 1 : 0;
   cm.seg = ps.seg;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) cm.pp[i] = i < b.cam.proj_dim ? x[b.cam.proj_off + i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cm.dk[i] = b.cam.dist_off >= 0 ? x[b.cam.dist_off + i] : 0.0;
   if (!cm.ok) return;
   Rigid Tcb, Twb, Tbw, Tpw, Twp;
   load_rigid(x, b.q_cb.off, b.t_cb.off, Tcb);
@@ -149,8 +155,8 @@ MC_HD void f1_project(const ReprojBatchView& b, const double* x, const F1Common&
   m3_mulv(cm.Tcp.C, pt, pc);
   pc[0] += cm.Tcp.r[0]; pc[1] += cm.Tcp.r[1]; pc[2] += cm.Tcp.r[2];
   double kp[2];
-  project(b.cam.model, b.cam.dist, x + b.cam.proj_off, b.cam.dist_off >= 0 ? x + b.cam.dist_off : x, pc, kp,
-          wantJ ? Jc : nullptr);
+  (void)x;
+  project(b.cam.model, b.cam.dist, cm.pp, cm.dk, pc, kp, wantJ ? Jc : nullptr);
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
   double s = b.sinv[k];
   out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
@@ -166,11 +172,17 @@ MC_HD void f1_chain_row(const ReprojBatchView& b, const F1Common& cm, const doub
   v3_cross(a, pc, ap);
   // lhs of (X * T_w_p), lhs of (T_c_b * T_b_w): TransformationBasic(q_c_b, t_c_b)
   chain_basic(a, ap, cm.rcb, row + 6, row + 9);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { row[6 + d] *= b.q_cb.scale; row[9 + d] *= b.t_cb.scale; }
+  MC_SCHED_FENCE();
   // rhs T_w_p = inverse(T_p_w): chain * boxTimes(X) * (-boxTimes(T_w_p)) = -chain * boxTimes(T_c_p)
   double u[3], v[3];
   chain_boxtimes(a, ap, cm.Tcp, u, v);
   u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
   chain_basic(u, v, cm.rpw, row + 12, row + 15);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { row[12 + d] *= b.qpw_scale; row[15 + d] *= b.tpw_scale; }
+  MC_SCHED_FENCE();
   // rhs T_b_w = inverse(T_w_b): chain * boxTimes(T_c_b) * (-boxTimes(T_b_w)) = -chain * boxTimes(X)
   chain_boxtimes(a, ap, cm.X, u, v);
   u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
@@ -183,11 +195,6 @@ MC_HD void f1_chain_row(const ReprojBatchView& b, const F1Common& cm, const doub
   row[18] = jd * b.toff.scale;
 #pragma unroll
   for (int d = 0; d < 6; ++d) row[d] = B[d] * b.coef_scale;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    row[6 + d] *= b.q_cb.scale; row[9 + d] *= b.t_cb.scale;
-    row[12 + d] *= b.qpw_scale; row[15 + d] *= b.tpw_scale;
-  }
 }
 // One corner: weighted core rows (2 x 19, row stride ld) and weighted residual e[2].
 MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,

@@ -22,3 +22,15 @@ for i, (name, nbatch, nt, nwg, fd, fl, rb) in enumerate(info):
     print("%-22s batches %3d terms %8d workgroups %7d (%.1f terms/wg) | " % (name, nbatch, nt, nwg, nt / max(1, nwg)) +
           "  ".join("%s %.3f" % ({0: "eval", 3: "jac", 2: "+gram", 1: "full", 4: "m4", 5: "m5"}[m], res[m][i]) for m in MODES) + " ms")
 print("total: " + "  ".join("mode%d %.3f" % (m, float(res[m].sum())) for m in res))
+
+if 'timing' not in os.environ.get('MULTICAL_HIP_LIB', ''):
+    sys.exit(0)
+ph = api.phase_cycles(True, 1)
+names = {0: "stage record", 1: "project+chain", 2: "wait rows", 3: "mfma gram", 4: "tiles->Msh", 5: "board flush", 6: "image flush",
+         8: "lidar eval", 9: "lidar wait", 10: "lidar band", 11: "lidar arrow", 12: "lidar oo",
+         16: "imu eval", 17: "imu wait", 18: "imu band", 19: "imu arrow", 20: "imu oo"}
+nwg = {0: info[0][3], 8: info[3][3], 16: info[2][3]}
+for base in (0, 8, 16):
+    tot = ph[base:base + 8].sum()
+    print("phases (%s), cycles per workgroup: " % ("k_reproj" if base == 0 else names[base].split()[0]) +
+          "  ".join("%s %.0f (%.0f%%)" % (names[i], ph[i] / max(1, nwg[base]), 100 * ph[i] / max(1.0, tot)) for i in range(base, base + 8) if i in names))
