@@ -133,6 +133,7 @@ struct Problem {
   //   oo[nob*nob]  value offset of other-block pair (o1, o2) when block(o1) <= block(o2), else -1
   //   oh[nob]      col_h of other block o
   //   ocolblk[G]   other block of each local other column
+  //   oinfo[nob*3] (block index, local column start, global column base) of other block o
   std::vector<int> chunk_tab;
   // Multi-GPU: value indices (into Cx) of the Hessian blocks that more than one rank's terms can write -- window
   // halos of the coefficient band and the blocks between global design variables.  Only these need the all-reduce;
@@ -670,6 +671,7 @@ inline void Problem::finalize() {
               for (int o2 = 0; o2 < nob; ++o2) chunk_tab.push_back(ob[4 * o1] <= ob[4 * o2] ? lookup(ob[4 * o1], ob[4 * o2]) : -1);
             for (int o = 0; o < nob; ++o) chunk_tab.push_back(col_h[ob[4 * o]]);
             for (int o = 0; o < nob; ++o) for (int cc = 0; cc < ob[4 * o + 1]; ++cc) chunk_tab.push_back(o);
+            for (int o = 0; o < nob; ++o) { chunk_tab.push_back(ob[4 * o]); chunk_tab.push_back(ob[4 * o + 2]); chunk_tab.push_back(ob[4 * o + 3]); }
             (void)G;
             c.tab_len = (int)chunk_tab.size() - c.tab_off;
             b.max_tab = std::max(b.max_tab, c.tab_len);

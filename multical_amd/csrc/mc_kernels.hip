@@ -483,6 +483,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
   const int* oo_slot = arrow_slot + nob * nb;
   const int* oh = oo_slot + nob * nob;
   const int* ocolblk = oh + nob;
+  const int* oinfo = ocolblk + G;   // nob x (block index, local column start, global column base), staged with the table
   __shared__ double red[4];
   constexpr bool build = BUILD;
   if (build) {
@@ -597,10 +598,10 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
       const int g = g0 + j;
       if (g > G || acc[j] == 0.0) continue;
       if (g == G) { atomic_add_f64(dc.rhs + b_pose_first_col(b) + 6 * (ch.pose_lo + bi) + ra, -acc[j]); continue; }
-      const int o = ocolblk[g], sc = g - oblk[4 * o + 2];
+      const int o = ocolblk[g], sc = g - oinfo[3 * o + 1];
       const int slot = arrow_slot[o * nb + bi];
       if (slot < 0) continue;
-      if (oblk[4 * o] < pb + bi) atomic_add_f64(dc.Cx + slot + ra * hcol[bi] + (ra * (ra + 1)) / 2 + sc, acc[j]);   // column = coefficient
+      if (oinfo[3 * o] < pb + bi) atomic_add_f64(dc.Cx + slot + ra * hcol[bi] + (ra * (ra + 1)) / 2 + sc, acc[j]);   // column = coefficient
       else atomic_add_f64(dc.Cx + slot + sc * oh[o] + (sc * (sc + 1)) / 2 + ra, acc[j]);                          // column = other
     }
   }
@@ -617,13 +618,13 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
       for (int r = 0; r < D; ++r) acc += row[r * ld + 36 + g1] * row[r * ld + 36 + g2];
     }
     if (acc == 0.0 || dc.build != 1) continue;
-    const int o1 = ocolblk[g1], s1 = g1 - oblk[4 * o1 + 2];
-    if (g2 == G) { atomic_add_f64(dc.rhs + oblk[4 * o1 + 3] + s1, -acc); continue; }
-    const int o2 = ocolblk[g2], s2 = g2 - oblk[4 * o2 + 2];
+    const int o1 = ocolblk[g1], s1 = g1 - oinfo[3 * o1 + 1];
+    if (g2 == G) { atomic_add_f64(dc.rhs + oinfo[3 * o1 + 2] + s1, -acc); continue; }
+    const int o2 = ocolblk[g2], s2 = g2 - oinfo[3 * o2 + 1];
     if (o1 == o2) {
       int slot = oo_slot[o1 * nob + o1];
       if (slot >= 0) atomic_add_f64(dc.Cx + slot + s2 * oh[o1] + (s2 * (s2 + 1)) / 2 + s1, acc);
-    } else if (oblk[4 * o1] < oblk[4 * o2]) {
+    } else if (oinfo[3 * o1] < oinfo[3 * o2]) {
       int slot = oo_slot[o1 * nob + o2];
       if (slot >= 0) atomic_add_f64(dc.Cx + slot + s2 * oh[o2] + (s2 * (s2 + 1)) / 2 + s1, acc);
     } else {
