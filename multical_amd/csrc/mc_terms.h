@@ -186,8 +186,10 @@ MC_HD void f1_chain_row(const ReprojBatchView& b, const F1Common& cm, const doub
   // rhs T_b_w = inverse(T_w_b): chain * boxTimes(T_c_b) * (-boxTimes(T_b_w)) = -chain * boxTimes(X)
   chain_boxtimes(a, ap, cm.X, u, v);
   u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
+  MC_SCHED_FENCE();
   double B[6];
   chain_JT(u, v, cm.r, cm.S, B);
+  MC_SCHED_FENCE();
   // time offset: B * (Phi_dot c)  (BSplineExpressions.cpp:538-541)
   double jd = 0;
 #pragma unroll
