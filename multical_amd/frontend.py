@@ -1,0 +1,808 @@
+"""The caller side of the hot path: a Python mirror of the `aslam_backend` / `aslam_splines` /
+`kalibr_errorterms` / `incremental_calibration` names that Multical's front-end uses to build its problem
+(kalibr_sensor_calibration/sensors_and_targets.py:274-305, 542-630, 1103-1246; calibrator.py:94-123), and the LOWERING
+PASS that turns the expression trees those calls create into the typed SoA batches of the C ABI.
+
+The objects here are symbolic: `T_c_b * T_w_b.inverse() * T_w_p` builds a small tree, `problem.addErrorTerm(err)` stores
+it, and `lower(problem)` pattern-matches every error term against the six shapes Multical creates (F1 reprojection,
+F3 accelerometer, F4 gyroscope, F5 LiDAR point-to-plane, F7 motion; F2 lives in kalibr_camera_calibration) and emits a
+`ProblemSpec` with the design variables in problem order and consecutive same-shaped terms merged into batches.  A term
+that matches none of the shapes raises `UnsupportedErrorTerm` -- this library has no CPU fallback; an integrator keeps
+such terms on the reference's CPU path.
+
+Names and argument meaning follow the boost.python exports (aslam_backend_python/src/BackendExpressions.cpp:83-245,
+python/aslam_backend/__init__.py:10-36, aslam_splines_python, kalibr_errorterms).  Numeric evaluation (`toScalar`,
+`toTransformationMatrix`) is implemented for what the front-end calls while building the problem (time expressions and
+the LiDAR sign check); it uses SciPy's B-spline evaluation and is not on the hot path.
+"""
+import numpy as np
+
+from . import spec as S
+
+CALIBRATION_GROUP_ID, HELPER_GROUP_ID = S.CALIBRATION_GROUP_ID, S.HELPER_GROUP_ID
+
+
+class UnsupportedErrorTerm(ValueError):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _quat2r(q):
+    """quat2r of sm_kinematics (quaternion_algebra.cpp): q = [x y z w]."""
+    x, y, z, w = q
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y + w * z), 2 * (x * z - w * y)],
+                     [2 * (x * y - w * z), w * w - x * x + y * y - z * z, 2 * (y * z + w * x)],
+                     [2 * (x * z + w * y), 2 * (y * z - w * x), w * w - x * x - y * y + z * z]])
+
+
+def _rotvec2r(th):
+    from .synth import rotvec_to_matrix
+    return rotvec_to_matrix(np.asarray(th, dtype=np.float64))
+
+
+class Transformation(object):
+    """sm.Transformation: rotation quaternion [x y z w] + translation (T = [C(q) t; 0 1])."""
+
+    def __init__(self, q_or_T=None, t=None):
+        if q_or_T is None:
+            self._q, self._t = np.array([0.0, 0.0, 0.0, 1.0]), np.zeros(3)
+        elif t is None:
+            from .synth import quat_from_matrix
+            T = np.asarray(q_or_T, dtype=np.float64)
+            self._q, self._t = quat_from_matrix(T[:3, :3]), T[:3, 3].copy()
+        else:
+            self._q, self._t = np.asarray(q_or_T, dtype=np.float64).copy(), np.asarray(t, dtype=np.float64).copy()
+
+    def q(self):
+        return self._q
+
+    def t(self):
+        return self._t
+
+    def T(self):
+        M = np.eye(4)
+        M[:3, :3], M[:3, 3] = _quat2r(self._q), self._t
+        return M
+
+
+# ------------------------------------------------------------------------------------------------ design variables
+class DesignVariable(object):
+    kind = None
+
+    def __init__(self, params):
+        self.params = np.asarray(params, dtype=np.float64).ravel().copy()
+        self._active = False
+        self.scaling = 1.0
+
+    def setActive(self, a):
+        self._active = bool(a)
+
+    def isActive(self):
+        return self._active
+
+
+class RotationQuaternionDv(DesignVariable):
+    kind = S.DV_ROTATION_QUATERNION
+
+    def toExpression(self):
+        return RotationExpression(("r_leaf", self))
+
+
+class EuclideanPointDv(DesignVariable):
+    kind = S.DV_EUCLIDEAN_POINT
+
+    def toExpression(self):
+        return EuclideanExpression(("e_leaf", self))
+
+
+class EuclideanDirection(DesignVariable):
+    kind = S.DV_EUCLIDEAN_DIRECTION
+
+    def toExpression(self):
+        return EuclideanExpression(("e_leaf", self))
+
+
+class Scalar(DesignVariable):
+    kind = S.DV_SCALAR
+
+    def __init__(self, v):
+        DesignVariable.__init__(self, [v])
+
+    def toExpression(self):
+        return ScalarExpression(("s_leaf", self))
+
+    def toScalar(self):
+        return float(self.params[0])
+
+    toValue = toScalar
+
+
+class TransformationDv(object):
+    """python/aslam_backend/__init__.py:10-36."""
+
+    def __init__(self, transformation, rotationActive=True, translationActive=True):
+        if not isinstance(transformation, Transformation):
+            raise RuntimeError("The transformation must be an sm transformation")
+        self.q = RotationQuaternionDv(transformation.q())
+        self.q.setActive(rotationActive)
+        self.t = EuclideanPointDv(transformation.t())
+        self.t.setActive(translationActive)
+        self.expression = TransformationExpression(("t_leaf", self.q, self.t))
+
+    def toExpression(self):
+        return self.expression
+
+    def numDesignVariables(self):
+        return 2
+
+    def getDesignVariable(self, i):
+        if i == 0:
+            return self.q
+        if i == 1:
+            return self.t
+        raise RuntimeError("Index out of bounds: %d >= 2" % i)
+
+    designVariable = getDesignVariable
+
+    def T(self):
+        return self.expression.toTransformationMatrix()
+
+
+# ------------------------------------------------------------------------------------------------ splines
+class BSpline(object):
+    """bsplines.BSpline (value spline) -- knots, coefficients (dim x n), order; enough of the interface for the front-end."""
+
+    def __init__(self, order, knots=None, coeffs=None):
+        self.order = int(order)
+        self.knots = None if knots is None else np.asarray(knots, dtype=np.float64).copy()
+        self.coeffs = None if coeffs is None else np.asarray(coeffs, dtype=np.float64).copy()
+
+    def splineOrder(self):
+        return self.order
+
+    def initConstantSpline(self, t_min, t_max, num_segments, constant):
+        """BSpline::initConstantSpline (bsplines/src/BSpline.cpp): uniform knots, every coefficient = constant."""
+        k = self.order
+        dt = (t_max - t_min) / num_segments
+        self.knots = t_min + (np.arange(num_segments + 2 * k - 1) - (k - 1)) * dt
+        c = np.asarray(constant, dtype=np.float64).ravel()
+        self.coeffs = np.repeat(c[:, None], num_segments + k - 1, axis=1)
+
+    def t_min(self):
+        return float(self.knots[self.order - 1])
+
+    def t_max(self):
+        return float(self.knots[-self.order])
+
+    def eval(self, t, derivative=0):
+        from scipy.interpolate import BSpline as _B
+        b = _B(self.knots, self.coeffs.T, self.order - 1, extrapolate=False)
+        t = min(max(t, self.t_min()), np.nextafter(self.t_max(), -np.inf))
+        return np.asarray(b.derivative(derivative)(t) if derivative else b(t), dtype=np.float64)
+
+
+class BSplinePose(BSpline):
+    """bsplines.BSplinePose with the rotation-vector parametrisation (curve value = [r; theta])."""
+
+    def transformation(self, t):
+        v = self.eval(t)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = _rotvec2r(v[3:]), v[:3]
+        return T
+
+
+class _SplineDv(object):
+    def __init__(self, spline):
+        self._spline = spline
+        self.active = True
+        self.group = HELPER_GROUP_ID
+
+    def spline(self):
+        return self._spline
+
+    def numDesignVariables(self):
+        return self._spline.coeffs.shape[1]
+
+
+class BSplinePoseDesignVariable(_SplineDv):
+    """aslam_splines BSplinePoseDesignVariable (ASP/src/BSplinePoseDesignVariable.cpp)."""
+
+    def transformationAtTime(self, time_expression, bufferTmin, bufferTmax):
+        if not isinstance(time_expression, ScalarExpression):
+            raise TypeError("transformationAtTime takes a ScalarExpression")
+        return TransformationExpression(("t_spline_at", self, time_expression, float(bufferTmin), float(bufferTmax)))
+
+    def transformation(self, t):
+        return TransformationExpression(("t_spline_at", self, ScalarExpression(float(t)), 0.0, 0.0))
+
+    def orientation(self, t):
+        return RotationExpression(("r_spline", self, float(t)))
+
+    def linearAcceleration(self, t):
+        return EuclideanExpression(("e_spline", self, float(t), "lin_acc"))
+
+    def angularVelocityBodyFrame(self, t):
+        return EuclideanExpression(("e_spline", self, float(t), "ang_vel_b"))
+
+    def angularAccelerationBodyFrame(self, t):
+        return EuclideanExpression(("e_spline", self, float(t), "ang_acc_b"))
+
+
+class EuclideanBSplineDesignVariable(_SplineDv):
+    def toEuclideanExpression(self, t, derivative_order):
+        return EuclideanExpression(("e_bias_spline", self, float(t), int(derivative_order)))
+
+
+def addSplineDesignVariables(problem, dvc, setActive=True, group_id=HELPER_GROUP_ID):
+    """incremental_calibration addSplineDesignVariables: every coefficient becomes a design variable of the group."""
+    dvc.active, dvc.group = bool(setActive), group_id
+    problem._add_spline(dvc)
+
+
+# ------------------------------------------------------------------------------------------------ expressions
+def _const3(v):
+    return EuclideanExpression(("e_const", np.asarray(v, dtype=np.float64).ravel().copy()))
+
+
+class ScalarExpression(object):
+    def __init__(self, node):
+        self.node = ("s_const", float(node)) if isinstance(node, (int, float, np.floating)) else node
+
+    def _wrap(self, o):
+        return o if isinstance(o, ScalarExpression) else ScalarExpression(float(o))
+
+    def __add__(self, o):
+        return ScalarExpression(("s_add", self, self._wrap(o)))
+
+    def __sub__(self, o):
+        return ScalarExpression(("s_sub", self, self._wrap(o)))
+
+    def __mul__(self, o):
+        return ScalarExpression(("s_mul", self, self._wrap(o)))
+
+    def __truediv__(self, o):
+        return ScalarExpression(("s_div", self, self._wrap(o)))
+
+    __div__ = __truediv__
+
+    def toScalar(self):
+        n = self.node
+        k = n[0]
+        if k == "s_const":
+            return n[1]
+        if k == "s_leaf":
+            return n[1].toScalar()
+        if k == "s_dot":
+            return float(np.dot(n[1].toEuclidean(), n[2].toEuclidean()))
+        a, b = n[1].toScalar(), n[2].toScalar()
+        return {"s_add": a + b, "s_sub": a - b, "s_mul": a * b, "s_div": a / b if k == "s_div" else 0.0}[k]
+
+    toValue = toScalar
+
+    def affine(self):
+        """(design variable or None, constant) if the expression is dv + constants, else None."""
+        n = self.node
+        if n[0] == "s_const":
+            return None, n[1]
+        if n[0] == "s_leaf":
+            return n[1], 0.0
+        if n[0] in ("s_add", "s_sub"):
+            a, b = n[1].affine(), n[2].affine()
+            if a is None or b is None or (a[0] is not None and b[0] is not None) or (n[0] == "s_sub" and b[0] is not None):
+                return None
+            return (a[0] if a[0] is not None else b[0]), (a[1] + b[1] if n[0] == "s_add" else a[1] - b[1])
+        return None
+
+
+class EuclideanExpression(object):
+    def __init__(self, node):
+        self.node = ("e_const", np.asarray(node, dtype=np.float64).ravel().copy()) if isinstance(node, (np.ndarray, list)) else node
+
+    def __add__(self, o):
+        return EuclideanExpression(("e_add", self, o))
+
+    def __sub__(self, o):
+        return EuclideanExpression(("e_sub", self, o))
+
+    def cross(self, o):
+        return EuclideanExpression(("e_cross", self, o))
+
+    def dot(self, o):
+        return ScalarExpression(("s_dot", self, o))
+
+    def toEuclidean(self):
+        n = self.node
+        k = n[0]
+        if k == "e_const":
+            return n[1]
+        if k == "e_leaf":
+            if n[1].kind == S.DV_EUCLIDEAN_DIRECTION:
+                return n[1].params.copy()
+            return n[1].params
+        if k == "e_from_t":
+            return n[1].toTransformationMatrix()[:3, 3]
+        if k == "e_rot_mul":
+            return n[1].toRotationMatrix() @ n[2].toEuclidean()
+        if k == "e_add":
+            return n[1].toEuclidean() + n[2].toEuclidean()
+        if k == "e_sub":
+            return n[1].toEuclidean() - n[2].toEuclidean()
+        if k == "e_cross":
+            return np.cross(n[1].toEuclidean(), n[2].toEuclidean())
+        if k == "e_bias_spline":
+            return n[1].spline().eval(n[2], n[3])
+        raise NotImplementedError("numeric value of %s is not needed to build the problem" % k)
+
+
+class HomogeneousExpression(object):
+    def __init__(self, node):
+        self.node = ("h_const", np.asarray(node, dtype=np.float64).ravel().copy()) if isinstance(node, (np.ndarray, list)) else node
+
+    def toHomogeneous(self):
+        n = self.node
+        if n[0] == "h_const":
+            return n[1]
+        return n[1].toTransformationMatrix() @ n[2].toHomogeneous()
+
+
+class RotationExpression(object):
+    def __init__(self, node):
+        self.node = node
+
+    def inverse(self):
+        return RotationExpression(("r_inv", self))
+
+    def __mul__(self, o):
+        if isinstance(o, RotationExpression):
+            return RotationExpression(("r_mul", self, o))
+        if not isinstance(o, EuclideanExpression):
+            o = _const3(o)
+        return EuclideanExpression(("e_rot_mul", self, o))
+
+    def toRotationMatrix(self):
+        n = self.node
+        k = n[0]
+        if k == "r_leaf":
+            return _quat2r(n[1].params)
+        if k == "r_inv":
+            return n[1].toRotationMatrix().T
+        if k == "r_mul":
+            return n[1].toRotationMatrix() @ n[2].toRotationMatrix()
+        if k == "r_from_t":
+            return n[1].toTransformationMatrix()[:3, :3]
+        if k == "r_spline":
+            return _rotvec2r(n[1].spline().eval(n[2])[3:])
+        raise NotImplementedError(k)
+
+
+class TransformationExpression(object):
+    def __init__(self, node):
+        self.node = ("t_const", np.asarray(node, dtype=np.float64)) if isinstance(node, np.ndarray) else node
+
+    def inverse(self):
+        return TransformationExpression(("t_inv", self))
+
+    def __mul__(self, o):
+        if isinstance(o, TransformationExpression):
+            return TransformationExpression(("t_mul", self, o))
+        if isinstance(o, HomogeneousExpression):
+            return HomogeneousExpression(("h_transformed", self, o))
+        raise TypeError("TransformationExpression * %s" % type(o).__name__)
+
+    def toRotationExpression(self):
+        return RotationExpression(("r_from_t", self))
+
+    def toEuclideanExpression(self):
+        return EuclideanExpression(("e_from_t", self))
+
+    def toTransformationMatrix(self):
+        n = self.node
+        k = n[0]
+        if k == "t_const":
+            return n[1]
+        if k == "t_leaf":
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = _quat2r(n[1].params), n[2].params
+            return T
+        if k == "t_inv":
+            T = n[1].toTransformationMatrix()
+            Ti = np.eye(4)
+            Ti[:3, :3], Ti[:3, 3] = T[:3, :3].T, -T[:3, :3].T @ T[:3, 3]
+            return Ti
+        if k == "t_mul":
+            return n[1].toTransformationMatrix() @ n[2].toTransformationMatrix()
+        if k == "t_spline_at":
+            return n[1].spline().transformation(n[2].toScalar())
+        raise NotImplementedError(k)
+
+
+# ------------------------------------------------------------------------------------------------ M-estimators
+class _MEst(object):
+    kind, param = S.MEST_NONE, 0.0
+
+
+class NoMEstimator(_MEst):
+    pass
+
+
+class HuberMEstimator(_MEst):
+    kind = S.MEST_HUBER
+
+    def __init__(self, k):
+        self.param = float(k)
+
+
+class CauchyMEstimator(_MEst):
+    kind = S.MEST_CAUCHY
+
+    def __init__(self, sigma2):
+        self.param = float(sigma2)
+
+
+class GemanMcClureMEstimator(_MEst):
+    kind = S.MEST_GEMAN_MCCLURE
+
+    def __init__(self, sigma2):
+        self.param = float(sigma2)
+
+
+class BlakeZissermanMEstimator(_MEst):
+    kind = S.MEST_BLAKE_ZISSERMAN
+
+    def __init__(self, df, pCut=0.999, wCut=0.1):
+        self.param = float(S.blake_zisserman_epsilon(int(df), pCut, wCut))
+
+
+# ------------------------------------------------------------------------------------------------ cameras / error terms
+class CameraGeometry(object):
+    """aslam_cv camera geometry: projection model + distortion with their parameter vectors (update() order)."""
+
+    def __init__(self, model, dist, projection, distortion=None):
+        self.model, self.dist = model, dist
+        self.projection = np.asarray(projection, dtype=np.float64).copy()
+        self.distortion = None if distortion is None else np.asarray(distortion, dtype=np.float64).copy()
+
+
+class Keypoint(object):
+    def setMeasurement(self, y):
+        self.y = np.asarray(y, dtype=np.float64).ravel().copy()
+
+    def setInverseMeasurementCovariance(self, invR):
+        self.invR = np.asarray(invR, dtype=np.float64).copy()
+
+
+class Frame(object):
+    def __init__(self):
+        self.geometry, self.keypoints = None, []
+
+    def setGeometry(self, g):
+        self.geometry = g
+
+    def addKeypoint(self, k):
+        self.keypoints.append(k)
+
+
+class ErrorTerm(object):
+    def __init__(self):
+        self.mest = NoMEstimator()
+
+    def setMEstimatorPolicy(self, m):
+        self.mest = m
+
+
+class SimpleReprojectionError(ErrorTerm):
+    """aslam_cv_error_terms SimpleReprojectionError(frame, keypointIndex, point)."""
+
+    def __init__(self, frame, keypoint_index, point):
+        ErrorTerm.__init__(self)
+        self.frame, self.index, self.point = frame, int(keypoint_index), point
+
+
+class EuclideanError(ErrorTerm):
+    """kalibr_errorterms EuclideanError(measurement, invR, predicted)."""
+
+    def __init__(self, measurement, invR, predicted):
+        ErrorTerm.__init__(self)
+        self.meas = np.asarray(measurement, dtype=np.float64).ravel().copy()
+        self.invR, self.predicted = np.asarray(invR, dtype=np.float64), predicted
+
+
+class ScalarError(ErrorTerm):
+    """kalibr_errorterms ScalarError(measurement, invR, predicted)."""
+
+    def __init__(self, measurement, invR, predicted):
+        ErrorTerm.__init__(self)
+        self.meas, self.invR, self.predicted = float(measurement), float(np.asarray(invR).ravel()[0]), predicted
+
+    def error(self):
+        return self.predicted.toScalar() - self.meas
+
+
+class BSplineMotionError(ErrorTerm):
+    def __init__(self, spline_dv, W, error_term_order):
+        ErrorTerm.__init__(self)
+        self.spline_dv, self.W, self.order = spline_dv, np.asarray(W, dtype=np.float64), int(error_term_order)
+
+
+BSplineEuclideanMotionError = BSplineMotionError
+
+
+def addMotionErrorTerms(problem, spline_dv, W, error_term_order):
+    problem.addErrorTerm(BSplineMotionError(spline_dv, W, error_term_order))
+
+
+class OptimizationProblem(object):
+    """incremental_calibration OptimizationProblem: design variables live in groups (first-insertion order of the groups,
+    insertion order inside a group, OptimizationProblem.cpp:123-137, 272-292), error terms in insertion order."""
+
+    def __init__(self):
+        self.dvs = []          # (DesignVariable | _SplineDv, group)
+        self.terms = []
+
+    def addDesignVariable(self, dv, group_id=HELPER_GROUP_ID):
+        if any(d is dv for d, _ in self.dvs):
+            raise RuntimeError("design variable already included")
+        self.dvs.append((dv, group_id))
+
+    def _add_spline(self, sdv):
+        self.dvs.append((sdv, sdv.group))
+
+    def addErrorTerm(self, e):
+        self.terms.append(e)
+
+    def removeErrorTerm(self, e):
+        self.terms = [t for t in self.terms if t is not e]
+
+
+# ------------------------------------------------------------------------------------------------ lowering pass
+def _isotropic(invR, what):
+    invR = np.atleast_2d(np.asarray(invR, dtype=np.float64))
+    d = invR[0, 0]
+    if not np.allclose(invR, d * np.eye(invR.shape[0]), rtol=1e-12, atol=0.0):
+        raise UnsupportedErrorTerm("%s: the HIP path takes isotropic inverse covariances" % what)
+    return float(np.sqrt(d))
+
+
+def _match_t_leaf(T):
+    return (T.node[1], T.node[2]) if T.node[0] == "t_leaf" else None
+
+
+def _match_spline_at(T):
+    if T.node[0] != "t_spline_at":
+        return None
+    _, sdv, time, lo, hi = T.node
+    aff = time.affine()
+    if aff is None or lo != hi:
+        return None
+    return sdv, aff[0], aff[1], lo
+
+
+def _match_reprojection(term):
+    """p = (T_c_b * inverse(T_w_b(t + d)) * inverse(T_p_w)) * const   (sensors_and_targets.py:571-611)"""
+    p = term.point.node
+    if p[0] != "h_transformed" or p[2].node[0] != "h_const":
+        return None
+    T = p[1].node
+    if T[0] != "t_mul" or T[1].node[0] != "t_mul":
+        return None
+    Tcb = _match_t_leaf(T[1].node[1])
+    inv_wb, inv_pw = T[1].node[2].node, T[2].node
+    if Tcb is None or inv_wb[0] != "t_inv" or inv_pw[0] != "t_inv":
+        return None
+    sp = _match_spline_at(inv_wb[1])
+    Tpw = _match_t_leaf(inv_pw[1])
+    if sp is None or Tpw is None:
+        return None
+    pt = p[2].node[1]
+    if pt.size != 4 or pt[3] != 1.0:
+        return None
+    kp = term.frame.keypoints[term.index]
+    return dict(geometry=term.frame.geometry, spline=sp[0], toff=sp[1], time=sp[2], pad=sp[3], q_cb=Tcb[0], t_cb=Tcb[1],
+                q_pw=Tpw[0], t_pw=Tpw[1], p=pt[:3], y=kp.y, sinv=_isotropic(kp.invR, "reprojection error"))
+
+
+def _match_lidar(term):
+    """-(n . t(T_p_l)) / (n . C(T_p_l) dir),  T_p_l = T_p_w * (T_w_b(t + d) * inverse(T_l_b)),  n = e_z
+    (sensors_and_targets.py:274-305)"""
+    n = term.predicted.node
+    if n[0] != "s_mul" or n[2].node != ("s_const", -1.0) or n[1].node[0] != "s_div":
+        return None
+    d, th = n[1].node[1].node, n[1].node[2].node
+    if d[0] != "s_dot" or th[0] != "s_dot":
+        return None
+    ez = np.array([0.0, 0.0, 1.0])
+    for v in (d[1], th[1]):
+        if v.node[0] != "e_const" or not np.array_equal(v.node[1], ez):
+            return None
+    if d[2].node[0] != "e_from_t" or th[2].node[0] != "e_rot_mul":
+        return None
+    Tpl = d[2].node[1]
+    rot, direction = th[2].node[1].node, th[2].node[2].node
+    if rot[0] != "r_from_t" or rot[1] is not Tpl or direction[0] != "e_const":
+        return None
+    T = Tpl.node
+    if T[0] != "t_mul" or T[2].node[0] != "t_mul":
+        return None
+    Tpw = _match_t_leaf(T[1])
+    sp = _match_spline_at(T[2].node[1])
+    inv_lb = T[2].node[2].node
+    if Tpw is None or sp is None or inv_lb[0] != "t_inv":
+        return None
+    Tlb = _match_t_leaf(inv_lb[1])
+    if Tlb is None:
+        return None
+    return dict(spline=sp[0], toff=sp[1], time=sp[2], pad=sp[3], q_lb=Tlb[0], t_lb=Tlb[1], q_pw=Tpw[0], t_pw=Tpw[1],
+                dir=direction[1], range=term.meas, sinv=float(np.sqrt(term.invR)))
+
+
+def _match_bias(e):
+    n = e.node
+    if n[0] == "e_bias_spline" and n[3] == 0:
+        return n[1], None, n[2]
+    if n[0] == "e_leaf" and n[1].kind == S.DV_EUCLIDEAN_POINT:
+        return None, n[1], None
+    return None
+
+
+def _spline_e(e, what):
+    n = e.node
+    return (n[1], n[2]) if n[0] == "e_spline" and n[3] == what else None
+
+
+def _match_gyro(term):
+    """C_i_b * w_b(t) + b_g(t)   (sensors_and_targets.py:1198-1212)"""
+    n = term.predicted.node
+    if n[0] != "e_add":
+        return None
+    rm, bias = n[1].node, _match_bias(n[2])
+    if bias is None or rm[0] != "e_rot_mul" or rm[1].node[0] != "r_leaf":
+        return None
+    w = _spline_e(rm[2], "ang_vel_b")
+    if w is None or (bias[2] is not None and bias[2] != w[1]):
+        return None
+    return dict(spline=w[0], t=w[1], q_ib=rm[1].node[1], bias_spline=bias[0], bias_dv=bias[1], meas=term.meas,
+                sinv=_isotropic(term.invR, "gyroscope error"))
+
+
+def _match_accel(term):
+    """C_i_b * (C_b_w (a_w - g_w) + w_dot_b x r_b + w_b x (w_b x r_b)) + b_a(t)   (sensors_and_targets.py:1152-1170)"""
+    n = term.predicted.node
+    if n[0] != "e_add":
+        return None
+    rm, bias = n[1].node, _match_bias(n[2])
+    if bias is None or rm[0] != "e_rot_mul" or rm[1].node[0] != "r_leaf":
+        return None
+    inner = rm[2].node
+    if inner[0] != "e_add" or inner[1].node[0] != "e_add":
+        return None
+    grav_part, lever, centripetal = inner[1].node[1].node, inner[1].node[2].node, inner[2].node
+    if grav_part[0] != "e_rot_mul" or grav_part[1].node[0] != "r_inv" or grav_part[1].node[1].node[0] != "r_spline":
+        return None
+    sdv, t = grav_part[1].node[1].node[1], grav_part[1].node[1].node[2]
+    diff = grav_part[2].node
+    if diff[0] != "e_sub" or _spline_e(diff[1], "lin_acc") != (sdv, t) or diff[2].node[0] != "e_leaf":
+        return None
+    g = diff[2].node[1]
+    if lever[0] != "e_cross" or _spline_e(lever[1], "ang_acc_b") != (sdv, t) or lever[2].node[0] != "e_leaf":
+        return None
+    r_b = lever[2].node[1]
+    if centripetal[0] != "e_cross" or _spline_e(centripetal[1], "ang_vel_b") != (sdv, t):
+        return None
+    c2 = centripetal[2].node
+    if c2[0] != "e_cross" or _spline_e(c2[1], "ang_vel_b") != (sdv, t) or c2[2].node[0] != "e_leaf" or c2[2].node[1] is not r_b:
+        return None
+    if bias[2] is not None and bias[2] != t:
+        return None
+    return dict(spline=sdv, t=t, q_ib=rm[1].node[1], r_b=r_b, g=g, bias_spline=bias[0], bias_dv=bias[1], meas=term.meas,
+                sinv=_isotropic(term.invR, "accelerometer error"))
+
+
+def lower(problem):
+    """OptimizationProblem -> (ProblemSpec, handles).  `handles[id(obj)]` is the spec handle of a design variable,
+    spline design variable or camera geometry."""
+    sp = S.ProblemSpec()
+    handles = {}
+    for dv, group in problem.dvs:
+        if isinstance(dv, _SplineDv):
+            s = dv.spline()
+            handles[id(dv)] = sp.add_spline(s.order, s.knots, s.coeffs, dv.active, group)
+        else:
+            handles[id(dv)] = sp.add_dv(dv.kind, dv.params, dv.isActive(), dv.scaling, group)
+
+    def h(obj):
+        if obj is None:
+            return -1
+        if id(obj) not in handles:
+            # a design variable the front-end never added to the problem: constant (inactive)
+            if isinstance(obj, _SplineDv):
+                s = obj.spline()
+                handles[id(obj)] = sp.add_spline(s.order, s.knots, s.coeffs, False, HELPER_GROUP_ID)
+            else:
+                handles[id(obj)] = sp.add_dv(obj.kind, obj.params, False, obj.scaling, HELPER_GROUP_ID)
+        return handles[id(obj)]
+
+    def camera(geom):
+        if id(geom) not in handles:
+            hp = sp.add_dv(S.DV_PROJECTION, geom.projection, False, 1.0, CALIBRATION_GROUP_ID)
+            hk = sp.add_dv(S.DV_DISTORTION, geom.distortion, False, 1.0, CALIBRATION_GROUP_ID) if geom.distortion is not None else -1
+            handles[id(geom)] = sp.add_camera(geom.model, geom.dist, hp, hk)
+        return handles[id(geom)]
+
+    run_key, run = None, None
+
+    def flush():
+        nonlocal run_key, run
+        if run is None:
+            return
+        kind = run_key[0]
+        if kind == "reproj":
+            first = np.concatenate([[0], np.cumsum(run["counts"])]).astype(np.int32)
+            sp.add_reprojection_batch(run["camera"], run["spline"], run["q_cb"], run["t_cb"], run["toff"], run["obs_time"],
+                                      run["obs_q"], run["obs_t"], first, np.array(run["y"]), np.array(run["p"]),
+                                      np.array(run["sinv"]), run["pad"], run["mest"].kind, run["mest"].param)
+        elif kind == "lidar":
+            sp.add_lidar_batch(run["spline"], run["toff"], run["q_lb"], run["t_lb"], np.array(run["t"]), np.array(run["dir"]),
+                               np.array(run["range"]), np.array(run["sinv"]), run["q_pw"], run["t_pw"], run["pad"],
+                               run["mest"].kind, run["mest"].param)
+        elif kind == "accel":
+            sp.add_accelerometer_batch(run["spline"], run["bias_spline"], run["bias_dv"], run["g"], run["q_ib"], run["r_b"],
+                                       np.array(run["t"]), np.array(run["meas"]), np.array(run["sinv"]), run["mest"].kind,
+                                       run["mest"].param)
+        elif kind == "gyro":
+            sp.add_gyroscope_batch(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], np.array(run["t"]),
+                                   np.array(run["meas"]), np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
+        run_key, run = None, None
+
+    def start(key, **fields):
+        nonlocal run_key, run
+        if key != run_key:
+            flush()
+            run_key, run = key, dict(fields)
+            return True
+        return False
+
+    for term in problem.terms:
+        mk = (term.mest.kind, term.mest.param)
+        if isinstance(term, BSplineMotionError):
+            flush()
+            sp.add_motion_term(h(term.spline_dv), term.W, term.order)
+            continue
+        if isinstance(term, SimpleReprojectionError):
+            m = _match_reprojection(term)
+            if m is None:
+                raise UnsupportedErrorTerm("reprojection error over an expression that is not T_c_b * T_w_b(t+d)^-1 * T_p_w^-1 * p")
+            key = ("reproj", id(m["geometry"]), id(m["spline"]), id(m["q_cb"]), id(m["t_cb"]), id(m["toff"]), m["pad"], mk)
+            if start(key, camera=camera(m["geometry"]), spline=h(m["spline"]), q_cb=h(m["q_cb"]), t_cb=h(m["t_cb"]),
+                     toff=h(m["toff"]), pad=m["pad"], mest=term.mest, obs_time=[], obs_q=[], obs_t=[], counts=[], y=[], p=[],
+                     sinv=[], last=None):
+                pass
+            obs_id = (m["time"], id(m["q_pw"]), id(m["t_pw"]))
+            if run["last"] != obs_id:        # a new image observation: same time, same target
+                run["obs_time"].append(m["time"]); run["obs_q"].append(h(m["q_pw"])); run["obs_t"].append(h(m["t_pw"]))
+                run["counts"].append(0); run["last"] = obs_id
+            run["counts"][-1] += 1
+            run["y"].append(m["y"]); run["p"].append(m["p"]); run["sinv"].append(m["sinv"])
+        elif isinstance(term, ScalarError):
+            m = _match_lidar(term)
+            if m is None:
+                raise UnsupportedErrorTerm("scalar error that is not Multical's point-to-plane form")
+            key = ("lidar", id(m["spline"]), id(m["toff"]), id(m["q_lb"]), id(m["t_lb"]), id(m["q_pw"]), id(m["t_pw"]), m["pad"], mk)
+            start(key, spline=h(m["spline"]), toff=h(m["toff"]), q_lb=h(m["q_lb"]), t_lb=h(m["t_lb"]), pad=m["pad"],
+                  mest=term.mest, t=[], dir=[], range=[], sinv=[], q_pw=[], t_pw=[])
+            run["t"].append(m["time"]); run["dir"].append(m["dir"]); run["range"].append(m["range"]); run["sinv"].append(m["sinv"])
+            run["q_pw"].append(h(m["q_pw"])); run["t_pw"].append(h(m["t_pw"]))
+        elif isinstance(term, EuclideanError):
+            m = _match_accel(term)
+            kind = "accel"
+            if m is None:
+                m, kind = _match_gyro(term), "gyro"
+            if m is None:
+                raise UnsupportedErrorTerm("euclidean error that is neither the accelerometer nor the gyroscope form")
+            key = (kind, id(m["spline"]), id(m["q_ib"]), id(m["bias_spline"]), id(m["bias_dv"]), id(m.get("g")), id(m.get("r_b")), mk)
+            start(key, spline=h(m["spline"]), bias_spline=h(m["bias_spline"]), bias_dv=h(m["bias_dv"]), q_ib=h(m["q_ib"]),
+                  g=h(m.get("g")), r_b=h(m.get("r_b")), mest=term.mest, t=[], meas=[], sinv=[])
+            run["t"].append(m["t"]); run["meas"].append(m["meas"]); run["sinv"].append(m["sinv"])
+        else:
+            raise UnsupportedErrorTerm("error term type %s is not lowered" % type(term).__name__)
+    flush()
+    return sp, handles
