@@ -49,6 +49,13 @@ struct DevCommon {
 };
 // phase timing marks: compiled in only with -DMC_PHASE_TIMING (a separate diagnostic build, scripts/build_timing_lib.sh):
 // even a disabled mark costs registers in kernels that already sit at the occupancy limit
+// Diagnostic sub-modes of a build pass (2: everything but the atomics, 3: stop before the gather / flush) exist in the
+// same diagnostic build only; in the product MC_MODE is the constant 1 and the branches below fold away.
+#ifdef MC_PHASE_TIMING
+#define MC_MODE(dc) ((dc).build)
+#else
+#define MC_MODE(dc) 1
+#endif
 #ifdef MC_PHASE_TIMING
 #define MC_MARK(slot)                                                                      \
   do {                                                                                     \
@@ -157,7 +164,7 @@ __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, c
     double v = wp * wq * Msh[kb * (kb + 1) / 2 + ka];
     int ca = min(lcp, lcq), cb = max(lcp, lcq);
     int addr = entry_addr(f, dc.col_h, ca, cb);
-    if (dc.build == 1 || v == 1.2345e-300) atomic_add_f64(dc.Cx + addr, v);
+    if (MC_MODE(dc) == 1 || v == 1.2345e-300) atomic_add_f64(dc.Cx + addr, v);
   }
   const int p0 = board_part ? M : 0, p1 = board_part ? nlive : M;
   for (int p = p0 + tid; p < p1; p += 256) {
@@ -165,7 +172,7 @@ __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, c
     double wp;
     f1_live(p, ncoef, rc0, coef_shift, w, glc, gk, lcp, kp_, wp);
     double v = -wp * Msh[19 * 20 / 2 + kp_];
-    if (dc.build == 1 || v == 1.2345e-300) atomic_add_f64(dc.rhs + global_col(f, lcp), v);
+    if (MC_MODE(dc) == 1 || v == 1.2345e-300) atomic_add_f64(dc.rhs + global_col(f, lcp), v);
   }
 }
 
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
       __syncthreads();
       MC_MARK(4);   // tiles -> Msh
       // board rows / columns of this observation
-      if (dc.build != 3) f1_flush(f, dc, Msh, cm.w, rc0, coef_shift, glc, gk, n_nb, n_glob, true, tid);
+      if (MC_MODE(dc) != 3) f1_flush(f, dc, Msh, cm.w, rc0, coef_shift, glc, gk, n_nb, n_glob, true, tid);
       last_nnb = n_nb;
       MC_MARK(5);   // board flush
       any_done = true; last_rc0 = rc0; last_shift = coef_shift; last_staged = fp_staged; last_fp_begin = fp_begin;
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
   if ((tid & 63) == 0) red[tid >> 6] = Jacc;
   __syncthreads();
   if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-  if (!BUILD || !any_done || dc.build == 3) return;
+  if (!BUILD || !any_done || MC_MODE(dc) == 3) return;
   // image-level part: everything that does not involve a board pose, through the last observation's footprint
   // (same camera, same time: same coefficient buffer, extrinsics and time-offset blocks)
   if (tid < 210) Msh[tid] = img_acc;
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
   // segment s are exactly the run [rlo[s], rhi[s]) (a failed term inside a run has an all-zero row).  A violation
   // would silently drop products, so it is checked and reported.
   if (tid > 0 && tid < T && beta0[tid] >= 0 && beta0[tid - 1] >= 0 && beta0[tid] < beta0[tid - 1]) atomicOr(dc.status, STATUS_INTERNAL);
-  if (dc.build == 3) return;
+  if (MC_MODE(dc) == 3) return;
   const int ecol = 36 + G;
   (void)ecol;
   const int rstride = D * ld;
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
         }
       }
     }
-    if (dc.build != 1) { if (acc[0] + acc[5] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    if (MC_MODE(dc) != 1) { if (acc[0] + acc[5] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
     const int h = hcol[bj];
 #pragma unroll
     for (int cb = 0; cb < 6; ++cb)
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
         }
       }
     }
-    if (dc.build != 1) { if (acc[0] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    if (MC_MODE(dc) != 1) { if (acc[0] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       const int g = g0 + j;
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
 #pragma unroll
       for (int r = 0; r < D; ++r) acc += row[r * ld + 36 + g1] * row[r * ld + 36 + g2];
     }
-    if (acc == 0.0 || dc.build != 1) continue;
+    if (acc == 0.0 || MC_MODE(dc) != 1) continue;
     const int o1 = ocolblk[g1], s1 = g1 - oinfo[3 * o1 + 1];
     if (g2 == G) { atomic_add_f64(dc.rhs + oinfo[3 * o1 + 2] + s1, -acc); continue; }
     const int o2 = ocolblk[g2], s2 = g2 - oinfo[3 * o2 + 1];
@@ -675,8 +682,8 @@ __global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, De
   if (lane == 0) dc.Jpart[jpart_base + blockIdx.x] = Jacc;
   if (!BUILD) return;
   __syncthreads();
-  if (dc.build == 3) return;
-  if (dc.build == 2) {
+  if (MC_MODE(dc) == 3) return;
+  if (MC_MODE(dc) == 2) {
     double tot = 0.0;
     for (int cb = 0; cb < C; ++cb)
       for (int ca = lane; ca <= cb; ca += 64) {

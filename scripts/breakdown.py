@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Per-kernel phase breakdown on the bench workload: build modes 0 (evaluate), 3 (Jacobians only), 2 (+Gram, no atomics), 1 (full)."""
+"""Per-kernel phase breakdown on the bench workload: build modes 0 (evaluate), 3 (Jacobians only), 2 (+Gram, no atomics), 1 (full).
+Modes 2 / 3 and the in-kernel phase marks need the diagnostic build: scripts/build_timing_lib.sh, then
+MULTICAL_HIP_LIB=$PWD/multical_amd/libmulticalhip_timing.so python scripts/breakdown.py (with the product library modes 2 / 3 run as 1)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
