@@ -143,6 +143,20 @@ int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double*
  * are zeroed by the call.  With shards, the caller sums d_J/d_Cx/d_rhs over ranks (RCCL all-reduce). */
 int mc_evaluate_error_device(mc_context* ctx, int use_mestimator, double* d_J, double* d_e, void* stream);
 int mc_build_system_device(mc_context* ctx, int use_mestimator, double* d_Cx, double* d_rhs, void* stream);
+/* ---- second backend: J^T for SparseCholeskyLinearSystemSolver -------------------------------------------------
+ * SparseCholeskyLinearSystemSolver::initMatrixStructureImplementation / buildSystem
+ * (aslam_backend/src/SparseCholeskyLinearSystemSolver.cpp:15-45) keep the Jacobian itself: J^T (j_cols x j_rows) in
+ * compressed-column form, one column per residual row whose entries are the term's active design variables in
+ * block-index order, structural zeros of padded spline coefficients included
+ * (CompressedColumnJacobianTransposeBuilder.hpp:20-56, CompressedColumnMatrix.hpp:236-304).  mc_jt_nnz: entry count
+ * (-2: the problem holds a BSplineMotionError, whose evaluateJacobians is "currently unsupported" in the reference too);
+ * mc_get_jt_pattern: col_ptr[j_rows + 1], row_ind[nnz]; mc_build_jacobian_transpose(_device): the weighted values.
+ * The caller forms rhs = J^T e with e from mc_evaluate_error, like the reference (rightMultiply). */
+int mc_jt_nnz(const mc_context* ctx, long long* nnz);
+int mc_get_jt_pattern(mc_context* ctx, int* col_ptr, int* row_ind);
+int mc_build_jacobian_transpose(mc_context* ctx, int use_mestimator, double* values_out);
+int mc_build_jacobian_transpose_device(mc_context* ctx, int use_mestimator, double* d_values, void* stream);
+
 /* per-term raw chi^2 of the last mc_evaluate_error (ErrorTerm::getRawSquaredError) */
 int mc_get_term_chi2(mc_context* ctx, double* chi2_out);
 

@@ -48,6 +48,10 @@ SIGNATURES = {
     "mc_revert_update": (C.c_int, [_ctx]),
     "mc_get_dv_params": (C.c_int, [_ctx, C.c_int, _dp]),
     "mc_device_status": (C.c_int, [_ctx]),
+    "mc_jt_nnz": (C.c_int, [_ctx, C.POINTER(C.c_longlong)]),
+    "mc_get_jt_pattern": (C.c_int, [_ctx, _ip, _ip]),
+    "mc_build_jacobian_transpose": (C.c_int, [_ctx, C.c_int, _dp]),
+    "mc_build_jacobian_transpose_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p]),
     "mc_shared_count": (C.c_int, [_ctx]),
     "mc_get_shared_indices": (C.c_int, [_ctx, _ip]),
     "mc_pack_shared": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),

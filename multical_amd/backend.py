@@ -188,6 +188,26 @@ class HipApi(object):
         if s:
             raise BackendError(self.lib.mc_last_error(self.ctx).decode())
 
+    def jt_nnz(self):
+        n = C.c_longlong()
+        rc = self.lib.mc_jt_nnz(self.ctx, C.byref(n))
+        if rc == -2:
+            raise BackendError("This is currently unsupported")      # BSplineMotionError::evaluateJacobians
+        self._chk(rc)
+        return n.value
+
+    def jt_pattern(self):
+        nnz = self.jt_nnz()
+        cp, ri = np.zeros(self.j_rows + 1, np.int32), np.zeros(nnz, np.int32)
+        self._chk(self.lib.mc_get_jt_pattern(self.ctx, cp.ctypes.data_as(C.POINTER(C.c_int)), ri.ctypes.data_as(C.POINTER(C.c_int))))
+        return cp, ri
+
+    def build_jacobian_transpose(self, use_mest=True):
+        out = np.zeros(self.jt_nnz())
+        self._chk(self.lib.mc_build_jacobian_transpose(self.ctx, int(use_mest), _dp(out)))
+        self.check_status()
+        return out
+
     def shared_indices(self):
         n = self.lib.mc_shared_count(self.ctx)
         out = np.zeros(max(n, 0), np.int32)
@@ -334,6 +354,76 @@ class HipBlockCholeskyLinearSystemSolver(object):
         U = self.Hessian()
         A = U + sp.triu(U, 1).T
         return float(self._rhs @ (A @ self._rhs))
+
+
+class HipSparseCholeskyLinearSystemSolver(object):
+    """Same surface as SparseCholeskyLinearSystemSolver (aslam_backend/src/SparseCholeskyLinearSystemSolver.cpp): keeps
+    J^T in compressed-column form (built on the GPU), rhs = J^T e, and factors J^T J (+ conditioner^2) on the host."""
+
+    def __init__(self, api):
+        self.api = api
+        self._useDiagonalConditioner = False
+        self._diag = None
+        self._values = None
+        self._rhs = None
+        self._e = None
+
+    def name(self):
+        return "hip_sparse_cholesky"
+
+    def initMatrixStructure(self, useDiagonalConditioner):
+        if not self.api.finalized:
+            self.api.finalize()
+        self._useDiagonalConditioner = bool(useDiagonalConditioner)
+        self._cp, self._ri = self.api.jt_pattern()
+        self._diag = np.ones(self.api.j_cols)
+        self._rhs = np.zeros(self.api.j_cols)
+
+    def JRows(self):
+        return self.api.j_rows
+
+    def JCols(self):
+        return self.api.j_cols
+
+    def evaluateError(self, nThreads=1, useMEstimator=True):
+        J, self._e = self.api.evaluate_error(useMEstimator, want_e=True)
+        return J
+
+    def Jacobian(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self._values, self._ri, self._cp), shape=(self.api.j_cols, self.api.j_rows))   # J^T
+
+    def buildSystem(self, nThreads=1, useMEstimator=True):
+        self._values = self.api.build_jacobian_transpose(useMEstimator)
+        self._rhs = self.Jacobian() @ self._e                      # J_transpose.rightMultiply(_e, _rhs)
+
+    def setConstantConditioner(self, diag):
+        self._diag = np.full(self.api.j_cols, float(diag))
+
+    def setConditioner(self, diag):
+        self._diag = _f64(diag).copy()
+
+    def solveSystem(self):
+        """cholmod factors [J^T diag] [J^T diag]^T = J^T J + diag^2 (pushDiagonalBlock, :56-58)."""
+        import scipy.sparse as sp
+        Jt = self.Jacobian()
+        A = (Jt @ Jt.T).tocsc()
+        if self._useDiagonalConditioner:
+            A = A + sp.diags(self._diag * self._diag)
+        U = sp.triu(A).tocsc()
+        x = HostSparseCholesky().solve(self.api.j_cols, U.indptr, U.indices, U.data, self._rhs)
+        if x is None:
+            return False, np.zeros(self.api.j_cols)
+        return True, x
+
+    def rhs(self):
+        return self._rhs
+
+    def e(self):
+        return self._e
+
+    def rhsJtJrhs(self):
+        return float(np.sum((self.Jacobian().T @ self._rhs) ** 2))   # |J rhs|^2 (leftMultiply, :121-126)
 
 
 class LevenbergMarquardtTrustRegionPolicy(object):

@@ -124,6 +124,19 @@ struct Problem {
   std::unordered_map<std::string, int> fp_lookup;
   std::vector<int> update_dvs;              // active dvs in block order
   std::vector<int> ofp_data, ofp_off;       // other-block footprints of the chunks
+  // J^T layout of a term of a chunk (SparseCholesky backend): its design variables sorted by block index are the pose
+  // buffer range, the 6 live bias coefficients and the single other blocks.  Per ofp, JT_STRIDE ints:
+  //   [role]                    constant part of the role's first element index (-1: inactive)
+  //   [MC_MAX_ROLES + role]     1 if the pose range sorts before the role (adds 6 * nbuf of the term)
+  //   [2*MC_MAX_ROLES + role]   1 if the bias range sorts before the role (adds 18)
+  //   [3*MC_MAX_ROLES]          elements per column without the pose range
+  std::vector<int> ofp_jt;
+  enum { JT_STRIDE = 3 * MC_MAX_ROLES + 1 };
+  // per global term: first value index of its J^T columns and elements per column; total count
+  std::vector<long long> jt_start;
+  std::vector<int> jt_epc;
+  long long jt_nnz = 0;
+  bool jt_supported = true;
   std::map<std::vector<int>, int> ofp_lookup;
   std::vector<int> pat_colptr, pat_rows, pat_roff, pat_cp0;   // block pattern as CSR
   // Slot tables of this rank's chunks, one contiguous record per chunk (copied to LDS by one coalesced read):
@@ -309,7 +322,9 @@ struct Problem {
     return id;
   }
   // Other-block footprint of a chunk.  `written` = (role, first block, n blocks), blocks of one role consecutive.
-  int internOtherFootprint(const std::vector<std::array<int, 3>>& written, int biasLo, int biasNbuf) {
+  // poseRole / biasRole: role ids of the two coefficient ranges; poseBlock0 / biasBlock0: first block of the splines (-1: inactive)
+  int internOtherFootprint(const std::vector<std::array<int, 3>>& written, int biasLo, int biasNbuf, int poseRole = 0,
+                           int poseBlock0 = -1, int biasRole = -1, int biasBlock0 = -1) {
     std::vector<int> key;
     key.push_back(biasLo); key.push_back(biasNbuf);
     for (auto& w : written) { key.push_back(w[0]); key.push_back(w[1]); key.push_back(w[2]); }
@@ -330,6 +345,28 @@ struct Problem {
         ofp_data.push_back(blkid); ofp_data.push_back(block_dim[blkid]); ofp_data.push_back(c); ofp_data.push_back(block_col[blkid]);
         c += block_dim[blkid];
       }
+    {  // J^T layout: sort the segments (pose range, live bias range, singles) by block index
+      struct Seg { int block, role, dims; };
+      std::vector<Seg> segs;
+      if (poseBlock0 >= 0) segs.push_back(Seg{poseBlock0, poseRole, 0});
+      for (auto& w : written) {
+        if (w[0] == biasRole && biasBlock0 >= 0) segs.push_back(Seg{biasBlock0, biasRole, 18});   // 6 live coefficients x 3
+        else segs.push_back(Seg{w[1], w[0], block_dim[w[1]] * w[2]});
+      }
+      std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b2) { return a.block < b2.block; });
+      std::vector<int> jt(JT_STRIDE, 0);
+      for (int r = 0; r < MC_MAX_ROLES; ++r) jt[r] = -1;
+      int cst = 0, poseSeen = 0, biasSeen = 0;
+      for (const Seg& sg : segs) {
+        jt[sg.role] = cst; jt[MC_MAX_ROLES + sg.role] = poseSeen; jt[2 * MC_MAX_ROLES + sg.role] = 0;
+        if (biasSeen && !(sg.role == biasRole && biasBlock0 >= 0)) jt[2 * MC_MAX_ROLES + sg.role] = 0;   // bias dims are part of cst
+        if (poseBlock0 >= 0 && sg.role == poseRole && sg.block == poseBlock0) poseSeen = 1;
+        else cst += sg.dims;
+        (void)biasSeen;
+      }
+      jt[3 * MC_MAX_ROLES] = cst;
+      ofp_jt.insert(ofp_jt.end(), jt.begin(), jt.end());
+    }
     return id;
   }
   // pattern cliques of the stream kinds: (first coefficient block, count, second range first, count, other blocks...)
@@ -350,6 +387,7 @@ struct Problem {
   std::vector<std::vector<std::array<int, 3>>> fp_written;
 
   void finalize();
+  void jtPattern(std::vector<int>& col_ptr, std::vector<int>& row_ind) const;
 };
 
 inline void Problem::finalize() {
@@ -444,7 +482,8 @@ inline void Problem::finalize() {
           if (blk(c_q) >= 0) written.push_back({F5_ROLE_QPW, blk(c_q), 1});
           if (blk(c_t) >= 0) written.push_back({F5_ROLE_TPW, blk(c_t), 1});
         }
-        int ofp = internOtherFootprint(written, biasLo, biasN);
+        int ofp = internOtherFootprint(written, biasLo, biasN, lidar ? (int)F5_ROLE_COEF : (int)IMU_ROLE_POSE, coef_block0,
+                                       lidar ? -1 : (int)IMU_ROLE_BIAS, (bs && bias_block0 >= 0) ? bias_block0 : -1);
         bool poseActive = coef_block0 >= 0;
         b.chunks.push_back(ChunkRec{c_first, c_count, poseActive ? c_lo : 0, poseActive ? c_hi - c_lo + 1 : 0, ofp, 0, 0, 0});
         b.chunk_time.push_back(c_time);
@@ -762,8 +801,86 @@ inline void Problem::finalize() {
       }
     std::sort(shared_idx.begin(), shared_idx.end());
   }
+  // ---- J^T (SparseCholesky backend) layout: elements per column and first value index of every term
+  jt_start.assign(n_terms + 1, 0); jt_epc.assign(n_terms, 0); jt_supported = true;
+  for (const Batch& b : batches) {
+    if (b.kind == KIND_MOTION) { jt_supported = false; continue; }   // BSplineMotionError has no evaluateJacobians in the reference either
+    for (const GroupRec& g : b.groups) {
+      int C = fp_data[fp_off[g.fp] + 1];
+      for (int k = 0; k < g.term_count; ++k) jt_epc[b.term_base + g.term_first + k] = C;
+    }
+    const bool poseActive = b.spline >= 0 && dvs[splines[b.spline].first_dv].block >= 0;
+    for (const ChunkRec& c : b.chunks) {
+      int fixed = ofp_jt[(size_t)c.ofp * JT_STRIDE + 3 * MC_MAX_ROLES];
+      for (int k = 0; k < c.term_count; ++k) {
+        int u = b.order[c.term_first + k];
+        jt_epc[b.term_base + u] = fixed + (poseActive ? 6 * b.term_nbuf[u] : 0);
+      }
+    }
+  }
+  {
+    int t = 0;
+    long long acc = 0;
+    for (const Batch& b : batches)
+      for (int k = 0; k < b.n_terms; ++k, ++t) { jt_start[t] = acc; acc += (long long)jt_epc[t] * b.dim; }
+    jt_start[n_terms] = acc;
+    jt_nnz = acc;
+  }
   update_dvs = block_dv;
   finalized = true;
+}
+
+// Symbolic J^T of SparseCholeskyLinearSystemSolver (CompressedColumnMatrix::appendJacobiansSymbolic,
+// AB/include/aslam/backend/implementation/CompressedColumnMatrix.hpp:236-285): per residual row one column holding the
+// scalar columns of the term's active design variables in block-index order.
+inline void Problem::jtPattern(std::vector<int>& col_ptr, std::vector<int>& row_ind) const {
+  if (!jt_supported) throw std::runtime_error("This is currently unsupported");   // BSplineMotionError::evaluateJacobians
+  if (jt_nnz > 0x7fffffffLL) throw std::overflow_error("J^T exceeds 2^31 entries");
+  col_ptr.assign(j_rows + 1, 0);
+  row_ind.assign((size_t)jt_nnz, 0);
+  auto emit = [&](int gterm, int dim, std::vector<int>& blocks) {
+    std::sort(blocks.begin(), blocks.end());
+    long long at = jt_start[gterm];
+    int epc = jt_epc[gterm];
+    for (int r = 0; r < dim; ++r) {
+      int k = 0;
+      for (int bk : blocks) for (int c = 0; c < block_dim[bk]; ++c) row_ind[(size_t)(at + (long long)r * epc + k++)] = block_col[bk] + c;
+      if (k != epc) throw std::logic_error("J^T layout mismatch");
+    }
+  };
+  for (const Batch& b : batches) {
+    for (const GroupRec& g : b.groups) {
+      std::vector<int> blocks;
+      for (auto& w : fp_written[g.fp]) for (int k = 0; k < w[2]; ++k) blocks.push_back(w[1] + k);
+      for (int k = 0; k < g.term_count; ++k) { std::vector<int> bl = blocks; emit(b.term_base + g.term_first + k, b.dim, bl); }
+    }
+    if (b.chunks.empty()) continue;
+    const SplineRec& sp = splines[b.spline];
+    const int coef_block0 = dvs[sp.first_dv].block;
+    const bool lidar = b.kind == KIND_LIDAR;
+    const SplineRec* bs = (!lidar && b.bias_spline >= 0) ? &splines[b.bias_spline] : nullptr;
+    const int bias_block0 = bs ? dvs[bs->first_dv].block : -1;
+    const int biasRole = lidar ? -1 : (int)IMU_ROLE_BIAS;
+    for (const ChunkRec& c : b.chunks) {
+      const int* of = &ofp_data[ofp_off[c.ofp]];
+      std::vector<int> fixed;
+      // the ofp lists the bias WINDOW of the chunk first (if any), then the single blocks
+      int nob = of[0], skip = (bs && bias_block0 >= 0) ? of[3] : 0;
+      for (int o = skip; o < nob; ++o) fixed.push_back(of[OFP_HDR + 4 * o]);
+      (void)biasRole;
+      for (int k = 0; k < c.term_count; ++k) {
+        int u = b.order[c.term_first + k];
+        std::vector<int> blocks = fixed;
+        if (coef_block0 >= 0) for (int i = 0; i < b.term_nbuf[u]; ++i) blocks.push_back(coef_block0 + b.term_lo[u] + i);
+        if (bs && bias_block0 >= 0) { int bseg = segmentOf(*bs, b.t[u]); for (int i = 0; i < bs->order; ++i) blocks.push_back(bias_block0 + bseg + i); }
+        emit(b.term_base + u, b.dim, blocks);
+      }
+    }
+  }
+  int col = 0;
+  for (const Batch& b : batches)
+    for (int k = 0; k < b.n_terms; ++k)
+      for (int r = 0; r < b.dim; ++r, ++col) col_ptr[col + 1] = col_ptr[col] + jt_epc[b.term_base + k];
 }
 
 }  // namespace mc

@@ -708,6 +708,100 @@ __global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, De
   }
 }
 
+
+// term evaluation for the J^T kernels: rc[] holds the element index of every role inside the term's CSC column
+__device__ __forceinline__ bool jt_eval(const LidarBatchView& b, const double* x, int u, bool useM, int* rc, const int*, int term_lo,
+                                        int nbuf, double* J, int ld, int* st) {
+  if (rc[F5_ROLE_COEF] >= 0) {
+    double t = b.t[u] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
+    if (!(t >= b.sp.t_min && t <= b.sp.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return false; }
+    int shift = spline_segment(b.sp, t) - term_lo;
+    if (shift < 0 || shift + S6 > nbuf) { *st = STATUS_BUFFER_EXCEEDED; return false; }
+    rc[F5_ROLE_COEF] += 6 * shift;
+  }
+  double e[1];
+  TermOut out;
+  if (!f5_term(b, x, u, useM, true, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return false; }
+  return true;
+}
+__device__ __forceinline__ bool jt_eval(const ImuBatchView& b, const double* x, int u, bool useM, int* rc, const int*, int, int,
+                                        double* J, int ld, int* st) {
+  double e[3];
+  TermOut out;
+  if (!imu_term(b, x, u, useM, true, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return false; }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second backend: J^T in compressed-column form for SparseCholeskyLinearSystemSolver
+// (AB/src/SparseCholeskyLinearSystemSolver.cpp:38-45; CompressedColumnJacobianTransposeBuilder.hpp:94-104).  The same
+// closed-form rows as buildSystem, but written out instead of multiplied: thread = term, the term functions write
+// straight into the term's CSC columns (row stride = elements per column), positioned by block-index order.
+struct JtView {
+  const long long* start;   // per global term: first value index
+  const int* epc;           // per global term: elements per column
+  const int* ofp_jt;        // per other-block footprint: role layout (Problem::ofp_jt)
+  double* values;
+};
+__global__ __launch_bounds__(64) void k_jt_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc, const GroupRec* __restrict__ groups,
+                                                  const F1Common* __restrict__ common, JtView jt) {
+  const GroupRec gr = groups[blockIdx.x];
+  const ReprojBatchView b = views[gr.batch];
+  const F1Common cm = common[blockIdx.x];
+  if (!cm.ok) { if (threadIdx.x == 0) atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); return; }
+  FpView f = fp_view(dc, gr.fp);
+  int rc[MC_MAX_ROLES];
+#pragma unroll
+  for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = f.rolecol[r];
+  if (rc[F1_ROLE_COEF] >= 0) {
+    int shift = cm.seg - f.coef_lo;
+    if (shift < 0 || shift + S6 > f.nbuf) { if (threadIdx.x == 0) atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); return; }
+    rc[F1_ROLE_COEF] += 6 * shift;
+  }
+  for (int k = threadIdx.x; k < gr.term_count; k += 64) {
+    const int term = gr.term_first + k, gterm = b.term_base_global + term;
+    double core[2 * F1_CORE], e[2];
+    TermOut out;
+    f1_term(b, dc.x, cm, term, dc.useM != 0, true, core, F1_CORE, e, out);
+    double* J = jt.values + jt.start[gterm];
+    const int epc = jt.epc[gterm];
+    f1_expand_row(core, cm.w, rc, J);
+    f1_expand_row(core + F1_CORE, cm.w, rc, J + epc);
+  }
+}
+__global__ __launch_bounds__(64) void k_jt_static(const StaticReprojBatchView* __restrict__ views, DevCommon dc,
+                                                  const GroupRec* __restrict__ groups, JtView jt) {
+  const GroupRec gr = groups[blockIdx.x];
+  const StaticReprojBatchView b = views[gr.batch];
+  FpView f = fp_view(dc, gr.fp);
+  for (int k = threadIdx.x; k < gr.term_count; k += 64) {
+    const int term = gr.term_first + k, gterm = b.term_base_global + term;
+    double e[2];
+    TermOut out;
+    f2_term(b, dc.x, term, dc.useM != 0, true, f.rolecol, jt.values + jt.start[gterm], jt.epc[gterm], e, out);
+  }
+}
+template <class View>
+__global__ __launch_bounds__(128) void k_jt_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
+                                                   const ChunkRec* __restrict__ chunks, JtView jt) {
+  const ChunkRec ch = chunks[blockIdx.x];
+  const View b = batches[ch.batch].v;
+  const int* __restrict__ order = batches[ch.batch].order;
+  const int* lay = jt.ofp_jt + (size_t)ch.ofp * (3 * MC_MAX_ROLES + 1);
+  const int* of = dc.ofp_data + dc.ofp_off[ch.ofp];
+  for (int k = threadIdx.x; k < ch.term_count; k += 128) {
+    const int u = order[ch.term_first + k], gterm = b.term_base_global + u;
+    const int nbuf = ch.pose_nb > 0 ? batches[ch.batch].term_nbuf[u] : 0;
+    int rc[MC_MAX_ROLES];
+#pragma unroll
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = lay[r] >= 0 ? lay[r] + lay[MC_MAX_ROLES + r] * 6 * nbuf : -1;
+    if (ch.pose_nb == 0) rc[0] = -1;
+    int st = 0;
+    const bool ok = jt_eval(b, dc.x, u, dc.useM != 0, rc, of, batches[ch.batch].term_lo[u], nbuf, jt.values + jt.start[gterm], jt.epc[gterm], &st);
+    if (!ok) atomicOr(dc.status, st);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BSplineMotionError (BSplineMotionError.hpp:62-77, 93-166): one lane per spline coefficient.
 struct MotionView {
@@ -881,6 +975,9 @@ struct mc_context {
   DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, Jpart2, J, dx;
   DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab, shared_idx;
   DevBuf<UpdRec> upd;
+  DevBuf<long long> jt_start;
+  DevBuf<int> jt_epc, ofp_jt;
+  DevBuf<double> jt_values;
   DevBuf<unsigned long long> phase;
   bool phase_on = false;
   std::vector<std::unique_ptr<DevBatch>> db;
@@ -891,6 +988,7 @@ struct mc_context {
   void uploadStructure();
   void launchAll(int build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
                  std::vector<hipEvent_t>* ev = nullptr);
+  void launchJt(int useM, double* dValues, hipStream_t st);
 };
 
 static thread_local std::string g_create_error;
@@ -1190,6 +1288,36 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   }
 }
 
+void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
+  if (!P.jt_supported) throw std::runtime_error("This is currently unsupported");   // what BSplineMotionError::evaluateJacobians throws
+  if (P.world > 1) throw std::logic_error("the J^T backend is single-GPU");
+  if (!jt_start.p) { jt_start.upload(P.jt_start); jt_epc.upload(P.jt_epc); ofp_jt.upload(P.ofp_jt); }
+  DevCommon dc;
+  std::memset(&dc, 0, sizeof dc);
+  dc.x = x.p; dc.fp_data = fp_data.p; dc.fp_off = fp_off.p; dc.col_h = col_h.p;
+  dc.ofp_data = ofp_data.p; dc.ofp_off = ofp_off.p; dc.status = status.p; dc.useM = useM; dc.build = 1;
+  JtView jt{jt_start.p, jt_epc.p, ofp_jt.p, dValues};
+  HIP_CHECK(hipMemsetAsync(dValues, 0, sizeof(double) * (size_t)P.jt_nnz, st));
+  if (lu[LAUNCH_REPROJ].n_items) {
+    LaunchUnit& L = lu[LAUNCH_REPROJ];
+    hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p);
+    hipLaunchKernelGGL(k_jt_reproj, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.common.p, jt);
+  }
+  if (lu[LAUNCH_STATIC].n_items) {
+    LaunchUnit& L = lu[LAUNCH_STATIC];
+    hipLaunchKernelGGL(k_jt_static, dim3(L.n_items), dim3(64), 0, st, L.sviews.p, dc, L.groups.p, jt);
+  }
+  if (lu[LAUNCH_IMU].n_items) {
+    LaunchUnit& L = lu[LAUNCH_IMU];
+    hipLaunchKernelGGL(k_jt_stream<ImuBatchView>, dim3(L.n_items), dim3(128), 0, st, L.iviews.p, dc, L.chunks.p, jt);
+  }
+  if (lu[LAUNCH_LIDAR].n_items) {
+    LaunchUnit& L = lu[LAUNCH_LIDAR];
+    hipLaunchKernelGGL(k_jt_stream<LidarBatchView>, dim3(L.n_items), dim3(128), 0, st, L.lviews.p, dc, L.chunks.p, jt);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 #define MC_TRY try {
 #define MC_CATCH(ctx, rv) } catch (const std::exception& ex) { (ctx)->err = ex.what(); return rv; }
 #define MC_NEED_FINAL(ctx) if (!(ctx)->P.finalized) throw std::logic_error("call mc_finalize first")
@@ -1342,6 +1470,39 @@ int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double*
   HIP_CHECK(hipStreamSynchronize(0));
   if (Cx_out) HIP_CHECK(hipMemcpy(Cx_out, ctx->Cx.p, sizeof(double) * ctx->P.nnz, hipMemcpyDeviceToHost));
   if (rhs_out) HIP_CHECK(hipMemcpy(rhs_out, ctx->rhs.p, sizeof(double) * ctx->P.j_cols, hipMemcpyDeviceToHost));
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_jt_nnz(const mc_context* ctx, long long* nnz) {
+  if (!ctx->P.finalized) return -1;
+  if (!ctx->P.jt_supported) return -2;
+  *nnz = ctx->P.jt_nnz;
+  return 0;
+}
+int mc_get_jt_pattern(mc_context* ctx, int* col_ptr, int* row_ind) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  std::vector<int> cp, ri;
+  ctx->P.jtPattern(cp, ri);
+  std::memcpy(col_ptr, cp.data(), sizeof(int) * cp.size());
+  std::memcpy(row_ind, ri.data(), sizeof(int) * ri.size());
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_build_jacobian_transpose_device(mc_context* ctx, int use_mestimator, double* d_values, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->launchJt(use_mestimator, d_values, (hipStream_t)stream);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_build_jacobian_transpose(mc_context* ctx, int use_mestimator, double* values_out) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!ctx->P.jt_supported) throw std::runtime_error("This is currently unsupported");
+  if (ctx->jt_values.n != (size_t)ctx->P.jt_nnz) ctx->jt_values.alloc((size_t)ctx->P.jt_nnz);
+  ctx->launchJt(use_mestimator, ctx->jt_values.p, 0);
+  HIP_CHECK(hipStreamSynchronize(0));
+  HIP_CHECK(hipMemcpy(values_out, ctx->jt_values.p, sizeof(double) * (size_t)ctx->P.jt_nnz, hipMemcpyDeviceToHost));
   return 0;
   MC_CATCH(ctx, -1)
 }

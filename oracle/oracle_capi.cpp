@@ -323,6 +323,48 @@ int orc_get_ccs(void* h, int* Cp, int* Ci, double* Cx, double* rhs) {
   if (rhs) std::memcpy(rhs, P->opt.solver.rhs.data(), sizeof(double) * P->opt.solver.JCols);
   return (int)cx.size();
 }
+// SparseCholeskyLinearSystemSolver's J^T in compressed-column form
+// (AB/include/aslam/backend/implementation/CompressedColumnJacobianTransposeBuilder.hpp:20-56, 94-104;
+//  CompressedColumnMatrix.hpp:236-304): one CSC column per residual row; its entries are the ACTIVE design variables of
+// the term's design-variable set sorted by block index (structural zeros of padded spline coefficients included);
+// values = getWeightedJacobians written in JacobianContainer (= block index) order.  Pass NULL arrays to get the count.
+int orc_build_jacobian_transpose(void* h, int useMest, int* col_ptr, int* row_ind, double* values) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  size_t nnz = 0;
+  int col = 0;
+  if (col_ptr) col_ptr[0] = 0;
+  for (auto& tp : P->terms) {
+    ErrorTerm* t = tp.get();
+    std::set<DesignVariable*> ds;
+    t->getDvs(ds);
+    std::vector<DesignVariable*> act;
+    for (DesignVariable* d : ds) if (d->active) act.push_back(d);
+    std::sort(act.begin(), act.end(), [](DesignVariable* a, DesignVariable* b) { return a->blockIndex < b->blockIndex; });
+    int epc = 0;
+    for (DesignVariable* d : act) epc += d->minimalDimensions();
+    if (row_ind)
+      for (int r = 0; r < t->dim; ++r) {
+        int k = 0;
+        for (DesignVariable* d : act) for (int c = 0; c < d->minimalDimensions(); ++c) row_ind[nnz + (size_t)r * epc + k++] = d->columnBase + c;
+      }
+    if (values) {
+      JacobianContainer jc(t->dim);
+      t->getWeightedJacobians(jc, useMest != 0);
+      int rowOffset = 0;
+      for (auto& kv : jc.jm) {
+        for (int c = 0; c < kv.second.r; ++c)
+          for (int r = 0; r < kv.second.c; ++r) values[nnz + (size_t)c * epc + rowOffset + r] = kv.second(c, r);
+        rowOffset += kv.second.c;
+      }
+      if (rowOffset != epc) throw std::runtime_error("Jacobian container does not cover the design-variable set of the term");
+    }
+    if (col_ptr) for (int r = 0; r < t->dim; ++r) { col_ptr[col + 1] = col_ptr[col] + epc; ++col; }
+    nnz += (size_t)epc * t->dim;
+  }
+  return (int)nnz;
+  ORC_CATCH(P, -1)
+}
 // dense weighted Jacobian rows + weighted error of one term (getWeightedJacobians / getWeightedError)
 int orc_term_weighted_jacobian(void* h, int term, int useMest, double* Jdense /* dim x JCols, row-major */, double* e) {
   Problem* P = (Problem*)h;

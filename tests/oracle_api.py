@@ -170,6 +170,14 @@ class OracleApi(object):
     def build_only(self, use_mest=True):
         self._chk(self.lib.orc_build_system(self.h, C.c_int(int(use_mest))))
 
+    def jacobian_transpose(self, use_mest=True):
+        """(col_ptr[j_rows+1], row_ind, values) of J^T as SparseCholeskyLinearSystemSolver builds it."""
+        self.lib.orc_build_jacobian_transpose.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        nnz = self._chk(self.lib.orc_build_jacobian_transpose(self.h, int(use_mest), None, None, None))
+        cp, ri, v = np.zeros(self.j_rows + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz)
+        self._chk(self.lib.orc_build_jacobian_transpose(self.h, int(use_mest), cp.ctypes.data, ri.ctypes.data, v.ctypes.data))
+        return cp, ri, v
+
     def term_weighted_jacobian(self, term, use_mest=True):
         dim, rb = C.c_int(), C.c_int()
         self.lib.orc_term_info(self.h, C.c_int(term), C.byref(dim), C.byref(rb))

@@ -121,3 +121,59 @@ def test_static_gpu_levenberg_marquardt_matches_oracle():
         if isinstance(v, int) and spec.ops[h][0] == "dv":
             a, b = g.dv_params(v), o.dv_params(oids[h])
             assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max()), (h, a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# second backend: J^T in compressed-column form (SparseCholeskyLinearSystemSolver, the default solver of Optimizer2 and
+# the one kalibr_calibrate_cameras runs on this problem shape)
+def test_oracle_jacobian_transpose_is_consistent(static_problem):
+    import scipy.sparse as sp
+    o = static_problem["oracle"]
+    J, e = o.evaluate_error(True)
+    cp, ri, v = o.jacobian_transpose(True)
+    Jt = sp.csc_matrix((v, ri, cp), shape=(o.j_cols, o.j_rows))
+    Cp, Ci, Cx, rhs = o.build_system(True)
+    U = sp.csc_matrix((Cx, Ci, Cp), shape=(o.j_cols, o.j_cols))
+    assert abs(sp.triu(Jt @ Jt.T) - U).max() <= 1e-13 * np.abs(Cx).max()
+    assert np.abs(Jt @ e - rhs).max() <= 1e-13 * np.abs(rhs).max()
+    assert np.all(np.diff(cp) > 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_mest", [True, False])
+def test_static_gpu_jacobian_transpose(static_problem, use_mest):
+    from multical_amd.backend import HipApi
+    o = static_problem["oracle"]
+    g = HipApi(0)
+    static_problem["spec"].emit(g)
+    g.finalize()
+    o.evaluate_error(use_mest)
+    cp, ri, v = o.jacobian_transpose(use_mest)
+    cpg, rig = g.jt_pattern()
+    assert np.array_equal(cp, cpg) and np.array_equal(ri, rig)           # bit-exact structure
+    g.evaluate_error(use_mest)
+    vg = g.build_jacobian_transpose(use_mest)
+    assert np.abs(vg - v).max() <= RTOL * np.abs(v).max()
+
+
+@pytest.mark.gpu
+def test_static_gpu_sparse_cholesky_solver_matches_block_solver(static_problem):
+    """LinearSolverTests.cpp:42-57 of the reference: the two solvers agree on J, e, rhs and dx."""
+    from multical_amd.backend import HipApi, HipBlockCholeskyLinearSystemSolver, HipSparseCholeskyLinearSystemSolver
+    g = HipApi(0)
+    static_problem["spec"].emit(g)
+    g.finalize()
+    a, b = HipBlockCholeskyLinearSystemSolver(g), HipSparseCholeskyLinearSystemSolver(g)
+    out = []
+    for s in (a, b):
+        s.initMatrixStructure(True)
+        J = s.evaluateError(1, True)
+        s.buildSystem(1, True)
+        s.setConstantConditioner(1.0)
+        ok, dx = s.solveSystem()
+        assert ok
+        out.append((J, s.e().copy(), s.rhs().copy(), dx, s.rhsJtJrhs()))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-9 * np.abs(out[0][2]).max()
+    assert np.abs(out[0][3] - out[1][3]).max() <= 1e-6 * np.abs(out[0][3]).max()
+    assert abs(out[0][4] - out[1][4]) <= 1e-9 * abs(out[0][4])

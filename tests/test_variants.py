@@ -164,3 +164,55 @@ def test_variant_gpu_parity(variants, name):
         assert np.abs(rhsg - rhs).max() <= RTOL * np.abs(rhs).max()
         assert np.all(Cxg[Cx == 0.0] == 0.0)
     g.check_status()
+
+
+def _without_motion(sp):
+    """op indices are handles, so the motion ops are blanked in place rather than removed"""
+    out = copy.deepcopy(sp)
+    keep = [(k, d) for k, d in out.ops]
+    # motion ops refer to splines but nothing refers to them: replace by removing from the END only is not possible in
+    # general, so rebuild with a map
+    idx_map, ops = {}, []
+    for i, (k, d) in enumerate(keep):
+        if k != "motion":
+            idx_map[i] = len(ops)
+            ops.append((k, d))
+    def rm(h):
+        return h if (h is None or h < 0) else idx_map[h]
+    for k, d in ops:
+        for f, v in list(d.items()):
+            if isinstance(v, (int, np.integer)) and not isinstance(v, bool) and (f in ("camera", "spline", "pose_spline", "bias_spline", "dv_proj", "dv_dist") or f.startswith("dv_")):
+                d[f] = rm(int(v))
+            elif isinstance(v, list) and (f.startswith("obs_dv") or f.startswith("dv_") or f.startswith("chain_dv")):
+                d[f] = [rm(h) for h in v]
+    out.ops = ops
+    return out
+
+
+@pytest.mark.gpu
+def test_jacobian_transpose_backend_on_the_spline_problem(small_problem):
+    """J^T (SparseCholesky backend) for F1 / F3 / F4 / F5 with time-offset padding: bit-exact structure, values 1e-9;
+    with the BSplineMotionError terms in the problem the call is refused like in the reference."""
+    from multical_amd.backend import BackendError, HipApi
+    from oracle_api import OracleApi
+    g0 = HipApi(0)
+    small_problem["spec"].emit(g0)
+    g0.finalize()
+    with pytest.raises(BackendError, match="unsupported"):
+        g0.jt_pattern()
+    sp = _without_motion(small_problem["spec"])
+    o = OracleApi()
+    sp.emit(o)
+    o.finalize()
+    g = HipApi(0)
+    sp.emit(g)
+    g.finalize()
+    for use_mest in (True, False):
+        o.evaluate_error(use_mest)
+        cp, ri, v = o.jacobian_transpose(use_mest)
+        cpg, rig = g.jt_pattern()
+        assert np.array_equal(cp, cpg) and np.array_equal(ri, rig)
+        g.evaluate_error(use_mest)
+        vg = g.build_jacobian_transpose(use_mest)
+        assert np.abs(vg - v).max() <= RTOL * np.abs(v).max()
+        assert np.array_equal(vg == 0.0, v == 0.0)           # structural zeros of the padded coefficients
