@@ -189,6 +189,61 @@ int mc_phase_cycles(mc_context* ctx, int use_mestimator, int build, unsigned lon
 /* number of multiprocessors etc. for reports; returns 0 and fills what it can */
 int mc_device_info(mc_context* ctx, char* name, int name_len, int* n_cu, double* hbm_gib);
 
+/* ---- host side above the device entry points (plain C++, multical_amd/csrc/mc_host.cpp) ------------------------
+ * The optimiser loop that calls the hot path and the sparse Cholesky that consumes its result stay on the host
+ * (north_star).  They are restated here so the backend runs end to end without the reference's build tree; an
+ * integrator who keeps aslam::backend::Optimizer2 and CHOLMOD needs none of this section. */
+
+/* scalar column base of every design-variable block in block order, n_blocks + 1 entries (what
+ * BlockCholeskyLinearSystemSolver::initMatrixStructureImplementation passes to SparseBlockMatrix as cumulative block
+ * sizes, BlockCholeskyLinearSystemSolver.cpp:47-54, shifted to start at 0) */
+int mc_get_block_bases(const mc_context* ctx, int* base);
+
+/* sparse_block_matrix::LinearSolverCholmod<MatrixXd> (sparse_block_matrix/linear_solver_cholmod.h:55-112): analyze once
+ * per structure, then factorize + solve per call.  The matrix is the upper-triangular scalar CCS that fillCCS emits;
+ * block_base (n_blocks + 1 entries, may be NULL) lets the ordering and the factor work on whole blocks.
+ * mc_cholesky_factorize returns 0, 1 = not positive definite (LinearSolverCholmod::solve returns false, :91-100), or
+ * -1 on misuse. */
+typedef struct mc_cholesky mc_cholesky;
+mc_cholesky* mc_cholesky_create(void);
+void mc_cholesky_destroy(mc_cholesky* h);
+const char* mc_cholesky_last_error(const mc_cholesky* h);
+int mc_cholesky_analyze(mc_cholesky* h, int n, const int* Cp, const int* Ci, int n_blocks, const int* block_base);
+int mc_cholesky_factorize(mc_cholesky* h, const double* Cx);
+int mc_cholesky_solve(mc_cholesky* h, const double* b, double* x);
+int mc_cholesky_stats(const mc_cholesky* h, int* n_dense_blocks, long long* nnz_factor, double* flops);
+int mc_cholesky_block_permutation(const mc_cholesky* h, int* perm /* n_blocks */);
+
+/* aslam::backend::Optimizer2Options (aslam_backend/include/aslam/backend/Optimizer2Options.hpp:9-42) with the two
+ * shared_ptr members replaced by selectors; mc_optimizer_options_default fills the reference's defaults. */
+enum { MC_POLICY_LEVENBERG_MARQUARDT = 0, MC_POLICY_GAUSS_NEWTON = 1, MC_POLICY_DOG_LEG = 2 };
+enum { MC_SOLVER_BLOCK_CHOLESKY = 0, MC_SOLVER_SPARSE_CHOLESKY = 1 };
+typedef struct mc_optimizer_options {
+  double convergenceJDescentRatioThreshold; /* 1e-5 */
+  double convergenceDeltaX;                 /* 1e-3 */
+  int maxIterations;                        /* 20 */
+  int verbose;                              /* 0 */
+  int nThreads;                             /* 4; a hint the GPU backend ignores */
+  int trustRegionPolicy;                    /* MC_POLICY_*: LevenbergMarquardt / GaussNewton / DogLeg TrustRegionPolicy */
+  double levenbergMarquardtLambdaInit;      /* 1e-3 (LevenbergMarquardtTrustRegionPolicy.cpp:7-13); Multical uses 10 */
+  int linearSolver;                         /* MC_SOLVER_*: BlockCholesky / SparseCholesky LinearSystemSolver */
+} mc_optimizer_options;
+/* SolutionReturnValue (aslam_backend_python/src/Optimizer.cpp:30-39) plus wall-clock per phase (the reference's
+ * "Optimizer2: ..." timers, Optimizer2.cpp:185-189) and the size of the host factorisation. */
+typedef struct mc_solution_return_value {
+  double JStart, JFinal;
+  int iterations, failedIterations;
+  double dXFinal, dJFinal;
+  int linearSolverFailure;
+  double seconds_initialize, seconds_evaluate_error, seconds_build_system, seconds_solve_system, seconds_state_update;
+  double factor_nnz, factor_flops;
+} mc_solution_return_value;
+void mc_optimizer_options_default(mc_optimizer_options* o);
+/* Optimizer2::optimize (Optimizer2.cpp:183-275) on the problem held by ctx; the state in ctx is the result
+ * (mc_get_dv_params).  Returns 0, or -1 with the message in mc_host_last_error(). */
+int mc_optimize(mc_context* ctx, const mc_optimizer_options* options, mc_solution_return_value* out);
+const char* mc_host_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

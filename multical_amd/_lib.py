@@ -64,6 +64,39 @@ SIGNATURES = {
     "mc_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, _ip, _dp]),
 }
 
+
+
+class OptimizerOptions(C.Structure):
+    """mc_optimizer_options (include/multical_hip.h)"""
+    _fields_ = [("convergenceJDescentRatioThreshold", C.c_double), ("convergenceDeltaX", C.c_double),
+                ("maxIterations", C.c_int), ("verbose", C.c_int), ("nThreads", C.c_int), ("trustRegionPolicy", C.c_int),
+                ("levenbergMarquardtLambdaInit", C.c_double), ("linearSolver", C.c_int)]
+
+
+class SolutionReturnValue(C.Structure):
+    """mc_solution_return_value (include/multical_hip.h)"""
+    _fields_ = [("JStart", C.c_double), ("JFinal", C.c_double), ("iterations", C.c_int), ("failedIterations", C.c_int),
+                ("dXFinal", C.c_double), ("dJFinal", C.c_double), ("linearSolverFailure", C.c_int),
+                ("seconds_initialize", C.c_double), ("seconds_evaluate_error", C.c_double),
+                ("seconds_build_system", C.c_double), ("seconds_solve_system", C.c_double),
+                ("seconds_state_update", C.c_double), ("factor_nnz", C.c_double), ("factor_flops", C.c_double)]
+
+
+SIGNATURES.update({
+    "mc_get_block_bases": (C.c_int, [_ctx, _ip]),
+    "mc_cholesky_create": (C.c_void_p, []),
+    "mc_cholesky_destroy": (None, [C.c_void_p]),
+    "mc_cholesky_last_error": (C.c_char_p, [C.c_void_p]),
+    "mc_cholesky_analyze": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _ip]),
+    "mc_cholesky_factorize": (C.c_int, [C.c_void_p, _dp]),
+    "mc_cholesky_solve": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mc_cholesky_stats": (C.c_int, [C.c_void_p, _ip, C.POINTER(C.c_longlong), _dp]),
+    "mc_cholesky_block_permutation": (C.c_int, [C.c_void_p, _ip]),
+    "mc_optimizer_options_default": (None, [C.POINTER(OptimizerOptions)]),
+    "mc_optimize": (C.c_int, [_ctx, C.POINTER(OptimizerOptions), C.POINTER(SolutionReturnValue)]),
+    "mc_host_last_error": (C.c_char_p, []),
+})
+
 _lib = None
 
 

@@ -11,8 +11,10 @@ control flow of the reference classes they stand in for:
 
 The residual / Jacobian / normal-equation work runs on the GPU; the sparse Cholesky solve stays on the host
 (north_star: "timed separately").  CHOLMOD is not installed here, so `solveSystem` factorises the same CCS
-matrix with SuperLU (scipy) in symmetric mode; the reference's own tests pin the solver only through
-solver-vs-solver agreement of dx (aslam_backend/test/LinearSolverTests.cpp:42-57).
+matrix with the C++ block Cholesky of csrc/host/block_cholesky.hpp; the reference's own tests pin the solver only
+through solver-vs-solver agreement of dx (aslam_backend/test/LinearSolverTests.cpp:42-57).  The same loop exists in
+C++ (csrc/host/optimizer2.hpp, `HipApi.optimize`); the Python classes here are the readable mirror the tests drive
+step by step.
 """
 import ctypes as C
 
@@ -138,6 +140,26 @@ class HipApi(object):
         self._chk(self.lib.mc_dv_block(self.ctx, dv, C.byref(b), C.byref(c)))
         return b.value, c.value
 
+    def block_bases(self):
+        out = np.empty(self.n_blocks + 1, np.int32)
+        self._chk(self.lib.mc_get_block_bases(self.ctx, _ip(out)))
+        return out
+
+    def optimize(self, **kw):
+        """Optimizer2::optimize in C++ (mc_optimize): keyword arguments are mc_optimizer_options fields.  Returns the
+        mc_solution_return_value as a dict."""
+        o = _lib.OptimizerOptions()
+        self.lib.mc_optimizer_options_default(C.byref(o))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown option %s" % k)
+            setattr(o, k, v)
+        r = _lib.SolutionReturnValue()
+        if self.lib.mc_optimize(self.ctx, C.byref(o), C.byref(r)) != 0:
+            raise BackendError(self.lib.mc_host_last_error().decode())
+        self.finalized = True
+        return {f: getattr(r, f) for f, _ in r._fields_}
+
     def pattern(self):
         Cp = np.empty(self.j_cols + 1, np.int32)
         Ci = np.empty(self.nnz, np.int32)
@@ -253,26 +275,48 @@ class HipApi(object):
 
 # ------------------------------------------------------------------------------------------------
 class HostSparseCholesky(object):
-    """Stand-in for sparse_block_matrix::LinearSolverCholmod::solve (linear_solver_cholmod.h:70-112) on the host.
-    Takes the upper-triangular CCS (Cp, Ci, Cx); returns None when the matrix is not positive definite."""
+    """sparse_block_matrix::LinearSolverCholmod::solve (linear_solver_cholmod.h:70-112) on the host: the C++ block
+    Cholesky of multical_amd/csrc/host/block_cholesky.hpp through its C entry points (CHOLMOD is not in this image).
+    Symbolic analysis once per pattern; `solve` returns None when the matrix is not positive definite."""
 
     def __init__(self):
-        self.perm_spec = "MMD_AT_PLUS_A"
+        self.lib = _lib.load()
+        self.h = self.lib.mc_cholesky_create()
+        self._pattern = None
 
-    def solve(self, n, Cp, Ci, Cx, b):
-        import scipy.sparse as sp
-        import scipy.sparse.linalg as spla
-        U = sp.csc_matrix((Cx, Ci, Cp), shape=(n, n))
-        A = (U + sp.triu(U, 1).T).tocsc()
+    def __del__(self):
         try:
-            lu = spla.splu(A, permc_spec=self.perm_spec, diag_pivot_thresh=0.0,
-                           options=dict(SymmetricMode=True))
-        except RuntimeError:
+            if self.h:
+                self.lib.mc_cholesky_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def analyze(self, n, Cp, Ci, block_base=None):
+        Cp, Ci = _i32(Cp), _i32(Ci)
+        bb = None if block_base is None else _i32(block_base)
+        rc = self.lib.mc_cholesky_analyze(self.h, n, _ip(Cp), _ip(Ci), 0 if bb is None else bb.size - 1, _ip(bb))
+        if rc != 0:
+            raise BackendError(self.lib.mc_cholesky_last_error(self.h).decode())
+        self._pattern = (n, Cp.ctypes.data, Cp.size, Ci.size)
+        self._keep = (Cp, Ci)
+
+    def stats(self):
+        nd, nnz, fl = C.c_int(), C.c_longlong(), C.c_double()
+        self.lib.mc_cholesky_stats(self.h, C.byref(nd), C.byref(nnz), C.byref(fl))
+        return dict(dense_blocks=nd.value, factor_nnz=nnz.value, factor_flops=fl.value)
+
+    def solve(self, n, Cp, Ci, Cx, b, block_base=None):
+        if self._pattern is None or self._pattern[0] != n or self._pattern[3] != len(Ci):
+            self.analyze(n, Cp, Ci, block_base)
+        Cx, b = _f64(Cx), _f64(b)
+        rc = self.lib.mc_cholesky_factorize(self.h, _dp(Cx))
+        if rc == 1:
             return None
-        d = lu.U.diagonal()
-        if not np.all(np.isfinite(d)) or np.any(d <= 0.0):   # no row pivoting: U's diagonal = LDL^T pivots
-            return None
-        x = lu.solve(b)
+        if rc != 0:
+            raise BackendError(self.lib.mc_cholesky_last_error(self.h).decode())
+        x = np.empty(n)
+        self.lib.mc_cholesky_solve(self.h, _dp(b), _dp(x))
         return x if np.all(np.isfinite(x)) else None
 
 
@@ -299,6 +343,7 @@ class HipBlockCholeskyLinearSystemSolver(object):
         self._Cp, self._Ci = self.api.pattern()
         n = self.api.j_cols
         self._diag_pos = self._Cp[1:] - 1          # last entry of every upper-triangular column = diagonal
+        self._host.analyze(n, self._Cp, self._Ci, self.api.block_bases())
         self._diag = np.zeros(n)
         self._Cx = np.zeros(self.api.nnz)
         self._rhs = np.zeros(n)
@@ -488,7 +533,7 @@ class LevenbergMarquardtTrustRegionPolicy(object):
 class Optimizer2Options(object):
     def __init__(self):
         self.convergenceDeltaX = 1e-3
-        self.convergenceJDescentRatioThreshold = 1e-3
+        self.convergenceJDescentRatioThreshold = 1e-5
         self.maxIterations = 20
         self.levenbergMarquardtLambdaInit = 1e-3
         self.doLevenbergMarquardt = True

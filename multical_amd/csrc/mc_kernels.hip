@@ -1432,6 +1432,13 @@ int mc_dv_block(const mc_context* ctx, int dv, int* block_index, int* column_bas
   *block_index = ctx->P.dvs[dv].block; *column_base = ctx->P.dvs[dv].col;
   return 0;
 }
+int mc_get_block_bases(const mc_context* ctx, int* base) {
+  if (!ctx->P.finalized || !base) return -1;
+  int c = 0;
+  for (int b = 0; b < ctx->P.n_blocks; ++b) { base[b] = c; c += ctx->P.block_dim[b]; }
+  base[ctx->P.n_blocks] = c;
+  return 0;
+}
 int mc_get_pattern(const mc_context* ctx, int* Cp, int* Ci) {
   if (!ctx->P.finalized) return -1;
   if (Cp) std::memcpy(Cp, ctx->P.Cp.data(), sizeof(int) * ctx->P.Cp.size());
