@@ -34,7 +34,8 @@ enum {
   MC_DV_EUCLIDEAN_DIRECTION = 3, /* EuclideanDirection    : given as a 3-vector, minimal 2 */
   MC_DV_SPLINE_COEFF = 4,        /* DesignVariableMappedVector<D> (created by mc_add_spline) */
   MC_DV_PROJECTION = 5,          /* DesignVariableAdapter<Projection>: 4/5/6 params         */
-  MC_DV_DISTORTION = 6           /* DesignVariableAdapter<Distortion>: 4 params             */
+  MC_DV_DISTORTION = 6,          /* DesignVariableAdapter<Distortion>: 4 params             */
+  MC_DV_MATRIX_BASIC = 7         /* MatrixBasic (created by mc_add_matrix_design_variable)  */
 };
 enum { MC_PROJ_PINHOLE = 0, MC_PROJ_OMNI = 1, MC_PROJ_DS = 2 };
 enum { MC_DIST_NONE = 0, MC_DIST_RADTAN = 1, MC_DIST_EQUI = 2 };
@@ -95,6 +96,22 @@ int mc_add_accelerometer_batch(mc_context* ctx, int pose_spline, int bias_spline
 int mc_add_gyroscope_batch(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_q_i_b, int n,
                            const double* t, const double* meas, const double* sqrt_inv_r, int mest_kind,
                            double mest_param);
+/* MatrixBasic (aslam_backend_expressions/src/MatrixBasic.cpp:10-47): 3x3 matrix A (9 values, row major) whose entries
+ * with a non-zero update_pattern (9 ints, row major) are the minimal parameters, numbered in row-major order of the
+ * pattern.  A matrix without free entries is a constant (the front-end's Ix / Iy / Iz selectors).  Returns the dv id. */
+int mc_add_matrix_design_variable(mc_context* ctx, const double* A, const int* update_pattern, int active, double scaling);
+/* The other two IMU models of multical_calibrate_sensors --imu-models.
+ * ScaledMisalignedImu accelerometer (sensors_and_targets.py:1449-1497):  M_accel * (C_i_b * (...)) + b_a, and with
+ * size_effect != NULL the ScaledMisalignedSizeEffectImu form (:1608-1661) with per-axis lever arms; size_effect lists the
+ * six design variables rx_i, ry_i, rz_i (EUCLIDEAN_POINT) and Ix, Iy, Iz (MATRIX_BASIC). */
+int mc_add_accelerometer_batch_sm(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_gravity, int dv_q_i_b,
+                                  int dv_r_b, int dv_M_accel, const int* size_effect, int n, const double* t,
+                                  const double* meas, const double* sqrt_inv_r, int mest_kind, double mest_param);
+/* ScaledMisalignedImu gyroscope (:1499-1550):  M_gyro * (C_gyro_b * w_b) + M_accel_gyro * (C_gyro_b * a_b) + b_g with
+ * C_gyro_b = C_gyro_i * C_i_b and a_b the body-frame specific force at the lever arm r_b. */
+int mc_add_gyroscope_batch_sm(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_q_i_b, int dv_q_gyro_i,
+                              int dv_M_gyro, int dv_M_accel_gyro, int dv_gravity, int dv_r_b, int n, const double* t,
+                              const double* meas, const double* sqrt_inv_r, int mest_kind, double mest_param);
 /* Multical LiDAR point-to-plane ScalarError (sensors_and_targets.py:274-305; kalibr/src/ScalarError.cpp:6-31). */
 int mc_add_lidar_batch(mc_context* ctx, int pose_spline, int dv_time_offset, int dv_q_l_b, int dv_t_l_b, int n,
                        const double* t, const double* dir /* [n,3] unit */, const double* range,
@@ -173,7 +190,7 @@ int mc_device_status(mc_context* ctx);
 /* Measurement aids.  The reference's phase timers ("Optimizer2: build Hessian", "...evaluate error",
  * aslam_backend/src/Optimizer2.cpp:185-189) are compiled out (Optimizer2.hpp:53-55).  Here every term family is ONE
  * kernel launch shared by all its batches: launch 0 reprojection (F1), 1 static reprojection (F2), 2 IMU (F3 + F4),
- * 3 lidar (F5), 4 motion (F7).  mc_build_system_timed runs one evaluateError (build = 0) or buildSystem (build = 1)
+ * 3 lidar (F5), 4 motion (F7), 5 IMU with the scale-misalignment models.  mc_build_system_timed runs one evaluateError (build = 0) or buildSystem (build = 1)
  * on the internal buffers with a HIP event pair around every launch and writes mc_num_launches() milliseconds.
  * mc_launch_counts: SURVEY.md 8(d) accounting of this rank's share -- buildSystem flops with every structurally
  * present block (padded zeros included, as the reference computes them), with the live blocks only, and the

@@ -112,6 +112,24 @@ class HipApi(object):
         self._chk(self.lib.mc_add_gyroscope_batch(self.ctx, pose_spline, bias_spline, dv_bias, dv_q_ib, t.size, _dp(t), _dp(meas),
                                                   _dp(sinv), mest, float(mest_param)))
 
+    def add_matrix_design_variable(self, A, pattern, active=True, scaling=1.0):
+        A, pattern = _f64(A).reshape(9), _i32(pattern).reshape(9)
+        return self._chk(self.lib.mc_add_matrix_design_variable(self.ctx, _dp(A), _ip(pattern), int(bool(active)), float(scaling)))
+
+    def add_accelerometer_batch_sm(self, pose_spline, bias_spline, dv_bias, dv_g, dv_q_ib, dv_r_b, dv_M, size_effect, t, meas, sinv,
+                                   mest=0, mest_param=0.0):
+        t, meas, sinv = _f64(t), _f64(meas), _f64(sinv)
+        se = None if size_effect is None else _i32(size_effect)
+        assert se is None or se.size == 6
+        self._chk(self.lib.mc_add_accelerometer_batch_sm(self.ctx, pose_spline, bias_spline, dv_bias, dv_g, dv_q_ib, dv_r_b, dv_M,
+                                                         _ip(se), t.size, _dp(t), _dp(meas), _dp(sinv), mest, float(mest_param)))
+
+    def add_gyroscope_batch_sm(self, pose_spline, bias_spline, dv_bias, dv_q_ib, dv_q_gi, dv_M, dv_Ma, dv_g, dv_r_b, t, meas, sinv,
+                               mest=0, mest_param=0.0):
+        t, meas, sinv = _f64(t), _f64(meas), _f64(sinv)
+        self._chk(self.lib.mc_add_gyroscope_batch_sm(self.ctx, pose_spline, bias_spline, dv_bias, dv_q_ib, dv_q_gi, dv_M, dv_Ma, dv_g,
+                                                     dv_r_b, t.size, _dp(t), _dp(meas), _dp(sinv), mest, float(mest_param)))
+
     def add_lidar_batch(self, spline, dv_toff, dv_q_lb, dv_t_lb, t, direction, rng, sinv, dv_q_pw, dv_t_pw, pad, mest=0,
                         mest_param=0.0):
         t, direction, rng, sinv = _f64(t), _f64(direction), _f64(rng), _f64(sinv)
@@ -243,7 +261,7 @@ class HipApi(object):
     def unpack_shared(self, d_buf, d_cx, stream=None):
         self._chk(self.lib.mc_unpack_shared(self.ctx, C.c_void_p(d_buf), C.c_void_p(d_cx), C.c_void_p(stream or 0)))
 
-    LAUNCH_NAMES = ("k_reproj", "k_group<StaticReproj>", "k_stream<Imu>", "k_stream<Lidar>", "k_motion")
+    LAUNCH_NAMES = ("k_reproj", "k_group<StaticReproj>", "k_stream<Imu>", "k_stream<Lidar>", "k_motion", "k_stream<ImuSm>")
 
     def launch_info(self):
         """[(kernel name, batches, terms, workgroups, flops_dense, flops_live, record_bytes)] per kernel launch of a build"""

@@ -23,14 +23,19 @@
 namespace mc {
 
 enum { DV_EUCLIDEAN_POINT = 0, DV_ROTATION_QUATERNION = 1, DV_SCALAR = 2, DV_EUCLIDEAN_DIRECTION = 3,
-       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6 };
-enum { KIND_REPROJ = 0, KIND_STATIC_REPROJ = 1, KIND_ACCEL = 2, KIND_GYRO = 3, KIND_LIDAR = 4, KIND_MOTION = 5 };
+       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6, DV_MATRIX_BASIC = 7 };
+enum { KIND_REPROJ = 0, KIND_STATIC_REPROJ = 1, KIND_ACCEL = 2, KIND_GYRO = 3, KIND_LIDAR = 4, KIND_MOTION = 5,
+       KIND_ACCEL_SM = 6, KIND_GYRO_SM = 7, N_KINDS = 8 };
+inline bool kindIsImu(int k) { return k == KIND_ACCEL || k == KIND_GYRO || k == KIND_ACCEL_SM || k == KIND_GYRO_SM; }
+inline bool kindIsAccel(int k) { return k == KIND_ACCEL || k == KIND_ACCEL_SM; }
+inline bool kindIsStream(int k) { return k == KIND_LIDAR || kindIsImu(k); }
 
 struct DvRec {
   int kind, dim, off, nparam, active;
   double scaling;
   int block = -1, col = -1;
   int spline = -1;
+  int mask = 0;   // MatrixBasic: update pattern, bit 3 * row + col
 };
 struct SplineRec {
   int order, dim, n_knots, n_coeff, n_seg, first_dv, param_off, knots_off, basis_off, active;
@@ -63,7 +68,10 @@ struct Batch {
   int mest = 0; double mest_a = 0;
   // shared ids
   int cam = -1, spline = -1, bias_spline = -1;
-  int dv[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // kind specific global dvs
+  // kind specific global dvs.  IMU kinds: 0 static bias, 1 gravity, 2 q_i_b, 3 r_b; scale-misalignment models add
+  // 4 M (accel: M_accel, gyro: M_gyro), 5 q_gyro_i, 6 M_accel_gyro, 7..9 rx_i ry_i rz_i, 10..12 Ix Iy Iz
+  int dv[14] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+  int size_effect = 0;
   double pad = 0;
   // per-term / per-observation host arrays
   std::vector<double> t, y, p, sinv, meas, range;
@@ -178,6 +186,20 @@ struct Problem {
     } else {
       x.insert(x.end(), params, params + n);
     }
+    dvs.push_back(d);
+    return (int)dvs.size() - 1;
+  }
+
+  // MatrixBasic (ABE/src/MatrixBasic.cpp:10-47): A row-major; the entries with a non-zero pattern are the minimal
+  // parameters, numbered in row-major order of the pattern (the column order of the selection matrix _B built at :17-25)
+  int addMatrixDv(const double* A, const int* pattern, int active, double scaling) {
+    DvRec d;
+    d.kind = DV_MATRIX_BASIC; d.scaling = scaling; d.off = (int)x.size(); d.nparam = 9; d.dim = 0; d.mask = 0;
+    for (int i = 0; i < 9; ++i) if (pattern[i] != 0) { d.mask |= 1 << i; ++d.dim; }
+    // a matrix without free entries has minimal dimension 0 and never reaches the optimiser (the front-end keeps
+    // Ix / Iy / Iz inactive, sensors_and_targets.py:1598-1606)
+    d.active = (active && d.dim > 0) ? 1 : 0;
+    x.insert(x.end(), A, A + 9);
     dvs.push_back(d);
     return (int)dvs.size() - 1;
   }
@@ -443,7 +465,7 @@ inline void Problem::finalize() {
         int fp = internFootprint(pattern, written, lo, coef_block0 >= 0 ? hi - lo + 1 : 0);
         pushGroup(b.obs_first[u], b.obs_first[u + 1] - b.obs_first[u], fp, u, b.t[u], 1 << 30);
       }
-    } else if (b.kind == KIND_LIDAR || b.kind == KIND_ACCEL || b.kind == KIND_GYRO) {
+    } else if (kindIsStream(b.kind)) {
       const bool lidar = b.kind == KIND_LIDAR;
       const SplineRec& s = splines[b.spline];
       const int coef_block0 = dvs[s.first_dv].block;
@@ -462,14 +484,19 @@ inline void Problem::finalize() {
       std::vector<std::pair<int, int>> fixedRoles;  // (role, dv)
       if (lidar) fixedRoles = {{F5_ROLE_QLB, b.dv[0]}, {F5_ROLE_TLB, b.dv[1]}, {F5_ROLE_TOFF, b.dv[2]}};
       else {
+        const bool sm = b.kind == KIND_ACCEL_SM || b.kind == KIND_GYRO_SM;
         if (!bs) fixedRoles.push_back({IMU_ROLE_BIAS, b.dv[0]});
-        if (b.kind == KIND_ACCEL) fixedRoles.push_back({IMU_ROLE_G, b.dv[1]});
+        if (kindIsAccel(b.kind) || sm) fixedRoles.push_back({IMU_ROLE_G, b.dv[1]});
         fixedRoles.push_back({IMU_ROLE_QIB, b.dv[2]});
-        if (b.kind == KIND_ACCEL) fixedRoles.push_back({IMU_ROLE_RB, b.dv[3]});
+        if (kindIsAccel(b.kind) || sm) fixedRoles.push_back({IMU_ROLE_RB, b.dv[3]});
+        if (sm) fixedRoles.push_back({IMU_ROLE_M, b.dv[4]});
+        if (b.kind == KIND_GYRO_SM) { fixedRoles.push_back({IMU_ROLE_QGI, b.dv[5]}); fixedRoles.push_back({IMU_ROLE_MA, b.dv[6]}); }
+        if (b.kind == KIND_ACCEL_SM && b.size_effect)
+          for (int j = 0; j < 3; ++j) fixedRoles.push_back({IMU_ROLE_RX + j, b.dv[7 + j]});
       }
       double fixed_s1 = 0, fixed_s2 = 0;
       for (auto& fr : fixedRoles) if (blk(fr.second) >= 0) { double d = dvs[fr.second].dim; fixed_s1 += d; fixed_s2 += d * d; }
-      const double fjac = lidar ? 3000.0 : (b.kind == KIND_ACCEL ? 6000.0 : 3000.0);
+      const double fjac = lidar ? 3000.0 : (b.kind == KIND_ACCEL ? 6000.0 : (b.kind == KIND_GYRO ? 3000.0 : 9000.0));
       int c_first = 0, c_count = 0, c_lo = 0, c_hi = -1, c_blo = 0, c_bhi = -1, c_q = -1, c_t = -1;
       double c_time = 0;
       auto closeChunk = [&]() {

@@ -90,6 +90,37 @@ inline void describeImu(Problem& P, bool accel, int pose_spline, int bias_spline
   P.batches.push_back(std::move(b));
 }
 
+// ScaledMisalignedImu / ScaledMisalignedSizeEffectImu (sensors_and_targets.py:1393-1661).  size_effect: NULL or the six
+// design variables rx_i, ry_i, rz_i (EuclideanPoint) and Ix, Iy, Iz (MatrixBasic).
+inline void describeImuSm(Problem& P, bool accel, int pose_spline, int bias_spline, int dv_bias, int dv_g, int dv_q_ib, int dv_r_b,
+                          int dv_M, int dv_q_gi, int dv_Ma, const int* size_effect, int n, const double* t, const double* meas,
+                          const double* sinv, int mest, double mest_a) {
+  requireOpen(P);
+  P.checkSpline(pose_spline, 6);
+  if (bias_spline >= 0) P.checkSpline(bias_spline, 3);
+  else P.checkDv(dv_bias, DV_EUCLIDEAN_POINT);
+  P.checkDv(dv_q_ib, DV_ROTATION_QUATERNION);
+  P.checkDv(dv_g, -1);
+  if (P.dvs[dv_g].kind != DV_EUCLIDEAN_DIRECTION && P.dvs[dv_g].kind != DV_EUCLIDEAN_POINT)
+    throw std::invalid_argument("gravity must be an EuclideanDirection or an EuclideanPoint");
+  P.checkDv(dv_r_b, DV_EUCLIDEAN_POINT);
+  P.checkDv(dv_M, DV_MATRIX_BASIC);
+  if (!accel) { P.checkDv(dv_q_gi, DV_ROTATION_QUATERNION); P.checkDv(dv_Ma, DV_MATRIX_BASIC); }
+  if (size_effect) {
+    if (!accel) throw std::invalid_argument("the size-effect model changes the accelerometer terms only");
+    for (int j = 0; j < 3; ++j) { P.checkDv(size_effect[j], DV_EUCLIDEAN_POINT); P.checkDv(size_effect[3 + j], DV_MATRIX_BASIC); }
+  }
+  checkMest(mest);
+  Batch b;
+  b.kind = accel ? KIND_ACCEL_SM : KIND_GYRO_SM; b.dim = 3; b.spline = pose_spline; b.bias_spline = bias_spline;
+  b.dv[0] = bias_spline >= 0 ? -1 : dv_bias; b.dv[1] = dv_g; b.dv[2] = dv_q_ib; b.dv[3] = dv_r_b; b.dv[4] = dv_M;
+  if (!accel) { b.dv[5] = dv_q_gi; b.dv[6] = dv_Ma; }
+  if (size_effect) { b.size_effect = 1; for (int j = 0; j < 6; ++j) b.dv[7 + j] = size_effect[j]; }
+  b.mest = mest; b.mest_a = mest_a; b.n_terms = n;
+  b.t.assign(t, t + n); b.meas.assign(meas, meas + 3 * (size_t)n); b.sinv.assign(sinv, sinv + n);
+  P.batches.push_back(std::move(b));
+}
+
 inline void describeLidar(Problem& P, int spline, int dv_toff, int dv_q_lb, int dv_t_lb, int n, const double* t,
                           const double* dir, const double* range, const double* sinv, const int* dv_q_pw, const int* dv_t_pw,
                           double pad, int mest, double mest_a) {

@@ -461,6 +461,28 @@ template <> struct StreamTraits<ImuBatchView> {
   }
 };
 
+template <> struct StreamTraits<ImuSmBatchView> {
+  enum { D = 3 };
+  static __device__ __forceinline__ int eval(const ImuSmBatchView& b, const double* x, int u, bool useM, bool wantJ,
+                                             const int* of, int pose_lo, int pose_nb, int, int,
+                                             double* J, int ld, double* e, TermOut& out, int* st) {
+    int rc[MC_MAX_ROLES];
+#pragma unroll
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? 36 + of[4 + r] : -1;
+    const double t = b.t[u];
+    if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    int beta0 = 0;
+    rc[IMU_ROLE_POSE] = -1;
+    if (pose_nb > 0) { beta0 = spline_segment(b.pose, t) - pose_lo; rc[IMU_ROLE_POSE] = 0; }
+    if (b.bias.order > 0 && rc[IMU_ROLE_BIAS] >= 0) {
+      if (!(t >= b.bias.t_min && t <= b.bias.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+      rc[IMU_ROLE_BIAS] += 3 * (spline_segment(b.bias, t) - of[2]);
+    }
+    if (!imu_sm_term(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    return beta0;
+  }
+};
+
 template <class View, bool BUILD>
 __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
                                                 const ChunkRec* __restrict__ chunks, StreamDims dm, int jpart_base) {
@@ -731,6 +753,13 @@ __device__ __forceinline__ bool jt_eval(const ImuBatchView& b, const double* x, 
   if (!imu_term(b, x, u, useM, true, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return false; }
   return true;
 }
+__device__ __forceinline__ bool jt_eval(const ImuSmBatchView& b, const double* x, int u, bool useM, int* rc, const int*, int, int,
+                                        double* J, int ld, int* st) {
+  double e[3];
+  TermOut out;
+  if (!imu_sm_term(b, x, u, useM, true, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return false; }
+  return true;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Second backend: J^T in compressed-column form for SparseCholeskyLinearSystemSolver
@@ -892,7 +921,7 @@ __global__ __launch_bounds__(256) void k_unpack(const int* __restrict__ idx, int
 }
 
 // Optimizer2::applyStateUpdate (Optimizer2.cpp:292-309) + every DesignVariable::updateImplementation
-struct UpdRec { int kind, dim, off, col; double scaling; };
+struct UpdRec { int kind, dim, off, col; double scaling; int mask; };
 __global__ __launch_bounds__(256) void k_update(const UpdRec* __restrict__ recs, int n, const double* __restrict__ dx, double* x) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -911,6 +940,11 @@ __global__ __launch_bounds__(256) void k_update(const UpdRec* __restrict__ recs,
     for (int k = 0; k < 9; ++k) C[k] = p[k];
     m3_mult(C, R, O);
     for (int k = 0; k < 9; ++k) p[k] = O[k];
+  } else if (u.kind == DV_MATRIX_BASIC) {
+    // A += unvec(B d): minimal parameter k is the k-th flagged entry in row-major order (ABE/src/MatrixBasic.cpp:17-25, 40-46)
+    int k = 0;
+    for (int idx = 0; idx < 9; ++idx)
+      if ((u.mask >> idx) & 1) p[idx] += d[k++] * u.scaling;
   } else {
     for (int k = 0; k < u.dim; ++k) p[k] += d[k] * u.scaling;
   }
@@ -946,7 +980,7 @@ struct DevBatch {
 
 // One kernel launch per term family: the batches (sensor streams) of a family share the launch through a device array
 // of their views; work items (groups / chunks) carry the index of their batch.
-enum { LAUNCH_REPROJ = 0, LAUNCH_STATIC = 1, LAUNCH_IMU = 2, LAUNCH_LIDAR = 3, LAUNCH_MOTION = 4, N_LAUNCH = 5 };
+enum { LAUNCH_REPROJ = 0, LAUNCH_STATIC = 1, LAUNCH_IMU = 2, LAUNCH_LIDAR = 3, LAUNCH_MOTION = 4, LAUNCH_IMU_SM = 5, N_LAUNCH = 6 };
 struct LaunchUnit {
   int n_batches = 0, n_terms = 0, n_items = 0, jpart_base = 0, n_jpart = 0, lds_bytes = 0;
   double flops_dense = 0, flops_live = 0, rec_bytes = 0;
@@ -958,6 +992,7 @@ struct LaunchUnit {
   DevBuf<StaticReprojBatchView> sviews;
   DevBuf<StreamBatch<ImuBatchView>> iviews;
   DevBuf<StreamBatch<LidarBatchView>> lviews;
+  DevBuf<StreamBatch<ImuSmBatchView>> xviews;
   DevBuf<MotionView> mviews;
   DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
   DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time
@@ -998,6 +1033,7 @@ static int launchOf(int kind) {
     case KIND_REPROJ: return LAUNCH_REPROJ;
     case KIND_STATIC_REPROJ: return LAUNCH_STATIC;
     case KIND_ACCEL: case KIND_GYRO: return LAUNCH_IMU;
+    case KIND_ACCEL_SM: case KIND_GYRO_SM: return LAUNCH_IMU_SM;
     case KIND_LIDAR: return LAUNCH_LIDAR;
     default: return LAUNCH_MOTION;
   }
@@ -1006,8 +1042,8 @@ static int launchOf(int kind) {
 void batchCounts(const Problem& P, const Batch& b, double& fd, double& fl, double& rec) {
   // buildSystem flops with every structurally present block (dense: what the reference computes, padded
   // zero blocks included), with the live blocks only, and the compulsory record bytes
-  static const double fjac[6] = {3500.0, 3500.0, 6000.0, 3000.0, 3000.0, 0.0};
-  static const double recb[6] = {72.0, 72.0, 52.0, 52.0, 64.0, 0.0};
+  static const double fjac[N_KINDS] = {3500.0, 3500.0, 6000.0, 3000.0, 3000.0, 0.0, 9000.0, 9000.0};
+  static const double recb[N_KINDS] = {72.0, 72.0, 52.0, 52.0, 64.0, 0.0, 52.0, 52.0};
   fd = b.flops_dense; fl = b.flops_live;
   for (const GroupRec& g : b.groups) {
     double s1 = 0, s2 = 0, l1 = 0, l2 = 0;
@@ -1044,7 +1080,7 @@ void mc_context::uploadStructure() {
   status.alloc(1);
   Cx.alloc(P.nnz); rhs.alloc(P.j_cols); e.alloc(P.j_rows); chi2.alloc(P.n_terms); J.alloc(1); dx.alloc(P.j_cols);
   std::vector<UpdRec> ur;
-  for (int dv : P.update_dvs) { const DvRec& d = P.dvs[dv]; ur.push_back(UpdRec{d.kind, d.dim, d.off, d.col, d.scaling}); }
+  for (int dv : P.update_dvs) { const DvRec& d = P.dvs[dv]; ur.push_back(UpdRec{d.kind, d.dim, d.off, d.col, d.scaling, d.mask}); }
   upd.upload(ur);
   db.clear();
   std::vector<GroupRec> groups[N_LAUNCH];
@@ -1053,6 +1089,7 @@ void mc_context::uploadStructure() {
   std::vector<StaticReprojBatchView> sviews;
   std::vector<StreamBatch<ImuBatchView>> iviews;
   std::vector<StreamBatch<LidarBatchView>> lviews;
+  std::vector<StreamBatch<ImuSmBatchView>> xviews;
   std::vector<MotionView> mviews;
   std::vector<ImageRec> images;
   for (int l = 0; l < N_LAUNCH; ++l) lu[l] = LaunchUnit();
@@ -1070,7 +1107,7 @@ void mc_context::uploadStructure() {
       const double share = 1.0 / P.world;   // this rank's part
       L.flops_dense += fd * share; L.flops_live += fl * share; L.rec_bytes += rec * share;
     }
-    const bool stream = b.kind == KIND_LIDAR || b.kind == KIND_ACCEL || b.kind == KIND_GYRO;
+    const bool stream = kindIsStream(b.kind);
     if (stream) {
       for (ChunkRec c : b.my_chunks) { c.batch = view_index; chunks[li].push_back(c); }
       d->order.upload(b.order); d->term_lo.upload(b.term_lo); d->term_nbuf.upload(b.term_nbuf);
@@ -1128,6 +1165,24 @@ void mc_context::uploadStructure() {
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
       sb.order = d->order.p; sb.term_lo = d->term_lo.p; sb.term_nbuf = d->term_nbuf.p;
       lviews.push_back(sb);
+    } else if (b.kind == KIND_ACCEL_SM || b.kind == KIND_GYRO_SM) {
+      d->t.upload(b.t); d->meas.upload(b.meas);
+      StreamBatch<ImuSmBatchView> sb;
+      ImuSmBatchView& v = sb.v;
+      v.pose = P.splineView(b.spline, knots.p, basis.p);
+      v.bias = P.splineView(b.bias_spline, knots.p, basis.p);
+      v.bias_dv = P.dvRef(b.dv[0]); v.g = P.dvRef(b.dv[1]); v.q_ib = P.dvRef(b.dv[2]); v.r_b = P.dvRef(b.dv[3]);
+      v.g_is_direction = P.dvs[b.dv[1]].kind == DV_EUCLIDEAN_DIRECTION ? 1 : 0;
+      v.pose_scale = 1.0; v.bias_scale = b.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
+      v.t = d->t.p; v.meas = d->meas.p; v.sinv = d->sinv.p;
+      v.mest = b.mest; v.mest_a = b.mest_a; v.is_accel = b.kind == KIND_ACCEL_SM ? 1 : 0;
+      v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
+      v.M = P.dvRef(b.dv[4]); v.M_mask = P.dvs[b.dv[4]].mask;
+      v.q_gi = P.dvRef(b.dv[5]); v.Ma = P.dvRef(b.dv[6]); v.Ma_mask = b.dv[6] >= 0 ? P.dvs[b.dv[6]].mask : 0;
+      v.size_effect = b.size_effect;
+      for (int j = 0; j < 3; ++j) { v.arm[j] = P.dvRef(b.dv[7 + j]); v.I_off[j] = b.dv[10 + j] >= 0 ? P.dvs[b.dv[10 + j]].off : -1; }
+      sb.order = d->order.p; sb.term_lo = d->term_lo.p; sb.term_nbuf = d->term_nbuf.p;
+      xviews.push_back(sb);
     } else if (b.kind == KIND_ACCEL || b.kind == KIND_GYRO) {
       d->t.upload(b.t); d->meas.upload(b.meas);
       StreamBatch<ImuBatchView> sb;
@@ -1192,19 +1247,21 @@ void mc_context::uploadStructure() {
       L.n_items = P.rank == 0 ? (int)mviews.size() : 0;
       L.n_jpart = L.n_items * L.motion_blocks;
       if (P.rank != 0) { L.flops_dense = L.flops_live = 0; }
-    } else if (l == LAUNCH_IMU || l == LAUNCH_LIDAR) {
+    } else if (l == LAUNCH_IMU || l == LAUNCH_LIDAR || l == LAUNCH_IMU_SM) {
       L.chunks.upload(chunks[l]);
       L.n_items = (int)chunks[l].size();
       L.n_jpart = L.n_items;
       StreamDims& dm = L.dims;
       dm.ld = (36 + ((dm.maxG + 1 + 6) / 7) * 7 + 1) & ~1;   // other columns + residual padded to whole 7-column tiles; even (16-byte aligned pairs)
-      const int dim = l == LAUNCH_IMU ? 3 : 1;
+      const int dim = l == LAUNCH_LIDAR ? 1 : 3;
       size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + dm.maxTab + 4;
       L.lds_bytes = (int)((size_t)dm.maxT * dim * dm.ld * sizeof(double) + ints * sizeof(int) + 16);
       if (L.lds_bytes > 150 * 1024) throw std::runtime_error("chunk tile exceeds the LDS budget");
       if (L.lds_bytes > 64 * 1024) {
         if (l == LAUNCH_LIDAR)
           HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<LidarBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+        else if (l == LAUNCH_IMU_SM)
+          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<ImuSmBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
         else
           HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<ImuBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
       }
@@ -1225,6 +1282,7 @@ void mc_context::uploadStructure() {
   lu[LAUNCH_STATIC].sviews.upload(sviews);
   lu[LAUNCH_IMU].iviews.upload(iviews);
   lu[LAUNCH_LIDAR].lviews.upload(lviews);
+  lu[LAUNCH_IMU_SM].xviews.upload(xviews);
   lu[LAUNCH_MOTION].mviews.upload(mviews);
   Jpart.alloc(std::max(1, n_jpart));
   Jpart2.alloc(256);
@@ -1266,6 +1324,10 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
       case LAUNCH_LIDAR:
         if (build) hipLaunchKernelGGL((k_stream<LidarBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         else hipLaunchKernelGGL((k_stream<LidarBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        break;
+      case LAUNCH_IMU_SM:
+        if (build) hipLaunchKernelGGL((k_stream<ImuSmBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else hipLaunchKernelGGL((k_stream<ImuSmBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_MOTION:
         hipLaunchKernelGGL(k_motion, dim3(L.motion_blocks, L.n_items), dim3(256), 0, st, L.mviews.p, dc, L.jpart_base);
@@ -1310,6 +1372,10 @@ void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
   if (lu[LAUNCH_IMU].n_items) {
     LaunchUnit& L = lu[LAUNCH_IMU];
     hipLaunchKernelGGL(k_jt_stream<ImuBatchView>, dim3(L.n_items), dim3(128), 0, st, L.iviews.p, dc, L.chunks.p, jt);
+  }
+  if (lu[LAUNCH_IMU_SM].n_items) {
+    LaunchUnit& L = lu[LAUNCH_IMU_SM];
+    hipLaunchKernelGGL(k_jt_stream<ImuSmBatchView>, dim3(L.n_items), dim3(128), 0, st, L.xviews.p, dc, L.chunks.p, jt);
   }
   if (lu[LAUNCH_LIDAR].n_items) {
     LaunchUnit& L = lu[LAUNCH_LIDAR];
@@ -1389,6 +1455,27 @@ int mc_add_gyroscope_batch(mc_context* ctx, int pose_spline, int bias_spline, in
                            const double* meas, const double* sqrt_inv_r, int mest_kind, double mest_param) {
   MC_TRY describeImu(ctx->P, false, pose_spline, bias_spline, dv_bias, -1, dv_q_i_b, -1, n, t, meas, sqrt_inv_r, mest_kind,
                      mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_matrix_design_variable(mc_context* ctx, const double* A, const int* update_pattern, int active, double scaling) {
+  MC_TRY requireOpen(ctx->P);
+  return ctx->P.addMatrixDv(A, update_pattern, active, scaling);
+  MC_CATCH(ctx, -1)
+}
+int mc_add_accelerometer_batch_sm(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_gravity, int dv_q_i_b,
+                                  int dv_r_b, int dv_M_accel, const int* size_effect, int n, const double* t, const double* meas,
+                                  const double* sqrt_inv_r, int mest_kind, double mest_param) {
+  MC_TRY describeImuSm(ctx->P, true, pose_spline, bias_spline, dv_bias, dv_gravity, dv_q_i_b, dv_r_b, dv_M_accel, -1, -1, size_effect, n,
+                       t, meas, sqrt_inv_r, mest_kind, mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_gyroscope_batch_sm(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_q_i_b, int dv_q_gyro_i,
+                              int dv_M_gyro, int dv_M_accel_gyro, int dv_gravity, int dv_r_b, int n, const double* t,
+                              const double* meas, const double* sqrt_inv_r, int mest_kind, double mest_param) {
+  MC_TRY describeImuSm(ctx->P, false, pose_spline, bias_spline, dv_bias, dv_gravity, dv_q_i_b, dv_r_b, dv_M_gyro, dv_q_gyro_i,
+                       dv_M_accel_gyro, nullptr, n, t, meas, sqrt_inv_r, mest_kind, mest_param);
   return 0;
   MC_CATCH(ctx, -1)
 }

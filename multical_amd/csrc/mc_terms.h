@@ -500,6 +500,254 @@ MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bo
 }
 
 // ------------------------------------------------------------------------------------------------
+// F3 / F4 with the front-end's other two IMU models (multical_calibrate_sensors --imu-models):
+//   ScaledMisalignedImu            (sensors_and_targets.py:1393-1550)
+//     accel: M_a (C_i_b (v1 + c)) + b_a - a_meas
+//     gyro : M_g (C_gyro_b w_b) + M_ag (C_gyro_b (v1 + c)) + b_g - w_meas,   C_gyro_b = C_gyro_i C_i_b
+//   ScaledMisalignedSizeEffectImu  (:1553-1661), accelerometer only (the gyroscope is inherited):
+//     accel: M_a (C_i_b v1 + sum_x I_x (C_i_b c_x)) + b_a - a_meas,   r_x = r_b + C_i_b^T rx_i
+// with v1 = C_b_w (a_w - g_w),  c(r) = wdot_b x r + w_b x (w_b x r).  M_* are MatrixBasic design variables
+// (ABE/src/MatrixBasic.cpp:10-47): 3x3, the entries flagged in the update pattern are the minimal parameters, in
+// row-major order of the pattern; d(M p)/d(entry (r, c)) = p[c] e_r (EuclideanExpressionNodeMatrixMultiply,
+// ABE/src/EuclideanExpressionNode.cpp:120-134, times MatrixBasic's selection matrix B).
+// Everything below the leading matrices has one shape: chain Kw into w_b, K0 into v1 and K_j into c(r_j) for every
+// lever arm j; the calibrated model of imu_term is the special case Kw = C_i_b (gyro) or K0 = K_1 = C_i_b (accel).
+enum { IMU_ROLE_M = 5, IMU_ROLE_QGI = 6, IMU_ROLE_MA = 7, IMU_ROLE_RX = 8 /* RY = 9, RZ = 10 */ };
+struct ImuSmBatchView : ImuBatchView {
+  DvRef M;          // accel: M_accel, gyro: M_gyro
+  DvRef q_gi, Ma;   // gyro: q_gyro_i, M_accel_gyro
+  DvRef arm[3];     // size effect: rx_i, ry_i, rz_i
+  int I_off[3];     // size effect: parameter offsets of Ix, Iy, Iz (MatrixBasic without free entries, 9 row-major values)
+  int M_mask, Ma_mask;   // update patterns, bit 3 * row + col
+  int size_effect;
+};
+// columns of a MatrixBasic design variable multiplying `vec`; f = sqrt(w) sqrtInvR scaling
+MC_HD void matrix_dv_columns(const double* vec, int mask, double f, double* J, int ld) {
+  int k = 0;
+  for (int idx = 0; idx < 9; ++idx)
+    if ((mask >> idx) & 1) { J[(idx / 3) * ld + k] = f * vec[idx % 3]; ++k; }
+}
+MC_HD void m3_add_skew_product(const double* A, const double* v, double* acc) {  // acc += A v^
+  double K[9], T[9];
+  m3_skew(v, K);
+  m3_mul(A, K, T);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] += T[i];
+}
+MC_HD bool imu_sm_term(const ImuSmBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol, double* J,
+                       int ld, double* e, TermOut& out) {
+  const double t = b.t[k];
+  PoseSample ps;
+  if (!pose_sample<3>(b.pose, x, t, ps)) return false;
+  double bw[1][S6];
+  double bias[3];
+  if (b.bias.order > 0) {
+    int bseg = spline_weights<S6, 1>(b.bias, t, bw);
+    if (bseg < 0) return false;
+    const double* cf = x + b.bias.param_off + (size_t)bseg * 3;
+    for (int d = 0; d < 3; ++d) {
+      double a = 0;
+      for (int i = 0; i < S6; ++i) a += cf[3 * i + d] * bw[0][i];
+      bias[d] = a;
+    }
+  } else {
+    bias[0] = x[b.bias_dv.off]; bias[1] = x[b.bias_dv.off + 1]; bias[2] = x[b.bias_dv.off + 2];
+  }
+  double Cib[9], R[9];
+  quat2r(x + b.q_ib.off, Cib);
+  double Cgi[9];
+  if (!b.is_accel) { quat2r(x + b.q_gi.off, Cgi); m3_mul(Cgi, Cib, R); }
+  else { for (int i = 0; i < 9; ++i) R[i] = Cib[i]; }
+  double om[3], al[3], G0w[9], G0a[9], G1[9], G1b[9];
+  body_rate(ps, ps.cd + 3, om, wantJ ? G0w : nullptr, G1);
+  body_rate(ps, ps.cdd + 3, al, wantJ ? G0a : nullptr, G1b);
+  double g[3];
+  if (b.g_is_direction) { const double* Cg = x + b.g.off; g[0] = Cg[9] * Cg[2]; g[1] = Cg[9] * Cg[5]; g[2] = Cg[9] * Cg[8]; }
+  else { g[0] = x[b.g.off]; g[1] = x[b.g.off + 1]; g[2] = x[b.g.off + 2]; }
+  double ag[3] = {ps.cdd[0] - g[0], ps.cdd[1] - g[1], ps.cdd[2] - g[2]}, v1[3];
+  m3_tmulv(ps.C, ag, v1);
+  // lever arms
+  const int na = (b.is_accel && b.size_effect) ? 3 : 1;
+  double rb[3] = {x[b.r_b.off], x[b.r_b.off + 1], x[b.r_b.off + 2]};
+  double rj[3][3], rho[3][3], cj[3][3], omxr[3][3];
+  for (int j = 0; j < na; ++j) {
+    rho[j][0] = rho[j][1] = rho[j][2] = 0.0;
+    if (na == 3) m3_tmulv(Cib, x + b.arm[j].off, rho[j]);     // C_i_b^T rx_i
+    for (int d = 0; d < 3; ++d) rj[j][d] = rb[d] + rho[j][d];
+    double alxr[3], oo[3];
+    v3_cross(al, rj[j], alxr);
+    v3_cross(om, rj[j], omxr[j]);
+    v3_cross(om, omxr[j], oo);
+    for (int d = 0; d < 3; ++d) cj[j][d] = alxr[d] + oo[d];
+  }
+  // value
+  const double* Mm = x + b.M.off;
+  double u1[3] = {0, 0, 0}, u2[3] = {0, 0, 0}, Tsum[3], s0[3], sj[3][3], pr[3];
+  if (b.is_accel) {
+    m3_mulv(R, v1, s0);
+    for (int d = 0; d < 3; ++d) Tsum[d] = s0[d];
+    for (int j = 0; j < na; ++j) {
+      m3_mulv(R, cj[j], sj[j]);
+      if (na == 3) { double t3[3]; m3_mulv(x + b.I_off[j], sj[j], t3); for (int d = 0; d < 3; ++d) Tsum[d] += t3[d]; }
+      else for (int d = 0; d < 3; ++d) Tsum[d] += sj[j][d];
+    }
+    m3_mulv(Mm, Tsum, pr);
+  } else {
+    double ab[3] = {v1[0] + cj[0][0], v1[1] + cj[0][1], v1[2] + cj[0][2]}, p1[3], p2[3];
+    m3_mulv(R, om, u1);
+    m3_mulv(R, ab, u2);
+    m3_mulv(Mm, u1, p1);
+    m3_mulv(x + b.Ma.off, u2, p2);
+    for (int d = 0; d < 3; ++d) pr[d] = p1[d] + p2[d];
+  }
+  double ev[3];
+  const double* m = b.meas + 3 * (size_t)k;
+  for (int d = 0; d < 3; ++d) ev[d] = pr[d] + bias[d] - m[d];
+  const double s = b.sinv[k];
+  out.chi2 = (s * s) * (ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+  out.w = mest_weight(b.mest, b.mest_a, out.chi2);
+  const double sw = (useM ? sqrt(out.w) : 1.0) * s;
+  e[0] = sw * ev[0]; e[1] = sw * ev[1]; e[2] = sw * ev[2];
+  if (!wantJ) return true;
+
+  // bias
+  if (rolecol[IMU_ROLE_BIAS] >= 0) {
+    if (b.bias.order > 0) {
+      for (int i = 0; i < S6; ++i)
+        for (int r = 0; r < 3; ++r) J[r * ld + rolecol[IMU_ROLE_BIAS] + 3 * i + r] = sw * b.bias_scale * bw[0][i];
+    } else {
+      for (int r = 0; r < 3; ++r) J[r * ld + rolecol[IMU_ROLE_BIAS] + r] = sw * b.bias_scale;
+    }
+  }
+  // leading matrices and the chains below them (sw folded in)
+  double Kw[9], K0[9], Kx[3][9], Qrot[9];   // Qrot: chain into the rotation R (accel: C_i_b; gyro: C_gyro_i C_i_b)
+  for (int i = 0; i < 9; ++i) { Kw[i] = 0.0; Qrot[i] = 0.0; }
+  if (b.is_accel) {
+    if (rolecol[IMU_ROLE_M] >= 0) matrix_dv_columns(Tsum, b.M_mask, sw * b.M.scale, J + rolecol[IMU_ROLE_M], ld);
+    double A[9];
+    for (int i = 0; i < 9; ++i) A[i] = sw * Mm[i];
+    m3_add_skew_product(A, s0, Qrot);
+    m3_mul(A, R, K0);
+    for (int j = 0; j < na; ++j) {
+      double Aj[9];
+      if (na == 3) m3_mul(A, x + b.I_off[j], Aj);
+      else for (int i = 0; i < 9; ++i) Aj[i] = A[i];
+      m3_add_skew_product(Aj, sj[j], Qrot);
+      m3_mul(Aj, R, Kx[j]);
+    }
+  } else {
+    if (rolecol[IMU_ROLE_M] >= 0) matrix_dv_columns(u1, b.M_mask, sw * b.M.scale, J + rolecol[IMU_ROLE_M], ld);
+    if (rolecol[IMU_ROLE_MA] >= 0) matrix_dv_columns(u2, b.Ma_mask, sw * b.Ma.scale, J + rolecol[IMU_ROLE_MA], ld);
+    double Aw[9], Aa[9];
+    const double* Ma = x + b.Ma.off;
+    for (int i = 0; i < 9; ++i) { Aw[i] = sw * Mm[i]; Aa[i] = sw * Ma[i]; }
+    m3_add_skew_product(Aw, u1, Qrot);
+    m3_add_skew_product(Aa, u2, Qrot);
+    m3_mul(Aw, R, Kw);
+    m3_mul(Aa, R, K0);
+    for (int i = 0; i < 9; ++i) Kx[0][i] = K0[i];
+  }
+  // aggregates over the lever arms
+  double KR[9], MW[9], KOm[9], Om[9], So[9], Sa[9];
+  m3_skew(om, So);
+  m3_skew(al, Sa);
+  m3_mul(So, So, Om);
+  for (int i = 0; i < 9; ++i) { Om[i] += Sa[i]; KR[i] = 0.0; MW[i] = Kw[i]; KOm[i] = 0.0; }
+  double Qib_extra[9];
+  for (int i = 0; i < 9; ++i) Qib_extra[i] = 0.0;
+  for (int j = 0; j < na; ++j) {
+    double Sr[9], Sor[9], tmp[9], T[9], KjOm[9];
+    m3_skew(rj[j], Sr);
+    m3_mul(Kx[j], Sr, T);
+    for (int i = 0; i < 9; ++i) KR[i] += T[i];
+    m3_skew(omxr[j], Sor);
+    m3_mul(So, Sr, tmp);
+    for (int i = 0; i < 9; ++i) tmp[i] += Sor[i];
+    m3_mul(Kx[j], tmp, T);
+    for (int i = 0; i < 9; ++i) MW[i] -= T[i];
+    m3_mul(Kx[j], Om, KjOm);                 // chain into r_j
+    for (int i = 0; i < 9; ++i) KOm[i] += KjOm[i];
+    if (na == 3) {
+      // r_j = r_b + inverse(C_i_b) * rj_i : the arm gets KjOm C_i_b^T, q_i_b gets -KjOm (C_i_b^T rj_i)^ C_i_b^T
+      double KC[9];
+      m3_mult(KjOm, Cib, KC);                // KjOm * C_i_b^T
+      const int col = rolecol[IMU_ROLE_RX + j];
+      if (col >= 0)
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) J[r * ld + col + c] = b.arm[j].scale * KC[3 * r + c];
+      double Srho[9], T2[9], T3[9];
+      m3_skew(rho[j], Srho);
+      m3_mul(KjOm, Srho, T2);
+      m3_mult(T2, Cib, T3);
+      for (int i = 0; i < 9; ++i) Qib_extra[i] -= T3[i];
+    }
+  }
+  // rotations: accel q_i_b <- Qrot ; gyro q_gyro_i <- Qrot, q_i_b <- Qrot C_gyro_i   (RotationExpressionNodeMultiply)
+  if (b.is_accel) {
+    if (rolecol[IMU_ROLE_QIB] >= 0)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_QIB] + c] = b.q_ib.scale * (Qrot[3 * r + c] + Qib_extra[3 * r + c]);
+  } else {
+    if (rolecol[IMU_ROLE_QGI] >= 0)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_QGI] + c] = b.q_gi.scale * Qrot[3 * r + c];
+    if (rolecol[IMU_ROLE_QIB] >= 0) {
+      double QC[9];
+      m3_mul(Qrot, Cgi, QC);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_QIB] + c] = b.q_ib.scale * QC[3 * r + c];
+    }
+  }
+  // r_b
+  if (rolecol[IMU_ROLE_RB] >= 0)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_RB] + c] = b.r_b.scale * KOm[3 * r + c];
+  // gravity: -K0 C_b_w Jg
+  double P[9];
+  m3_mult(K0, ps.C, P);
+  if (rolecol[IMU_ROLE_G] >= 0) {
+    if (b.g_is_direction) {
+      const double* Cg = x + b.g.off;
+      const double mg = Cg[9];
+      double c0[3] = {-mg * Cg[0], -mg * Cg[3], -mg * Cg[6]}, c1[3] = {mg * Cg[1], mg * Cg[4], mg * Cg[7]}, o0[3], o1[3];
+      m3_mulv(P, c0, o0);
+      m3_mulv(P, c1, o1);
+      for (int r = 0; r < 3; ++r) {
+        J[r * ld + rolecol[IMU_ROLE_G]] = -b.g.scale * o0[r];
+        J[r * ld + rolecol[IMU_ROLE_G] + 1] = -b.g.scale * o1[r];
+      }
+    } else {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_G] + c] = -b.g.scale * P[3 * r + c];
+    }
+  }
+  // pose coefficients: block i = [ wdd_i P | w_i Q0 + wd_i Q1 + wdd_i Q2 ]
+  if (rolecol[IMU_ROLE_POSE] >= 0) {
+    double CbwS[9], Kv1[9], KC[9], T1[9], T2[9], T3[9], Q0[9], Q1[9], Q2[9];
+    m3_tmul(ps.C, ps.S, CbwS);
+    m3_skew(v1, Kv1);
+    m3_mul(K0, Kv1, KC);
+    m3_mul(KC, CbwS, T1);       // K0 v1^ C_b_w S
+    m3_mul(KR, G0a, T2);
+    m3_mul(MW, G0w, T3);
+    for (int i = 0; i < 9; ++i) Q0[i] = -T1[i] - T2[i] + T3[i];
+    m3_mul(MW, G1, Q1);
+    m3_mul(KR, G1, Q2);
+    for (int i = 0; i < 9; ++i) Q2[i] = -Q2[i];
+    const double f = b.pose_scale;
+    for (int i = 0; i < S6; ++i) {
+      const double w0 = ps.w[0][i], w1 = ps.w[1][i], w2 = ps.w[2][i];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          J[r * ld + rolecol[IMU_ROLE_POSE] + 6 * i + c] = f * w2 * P[3 * r + c];
+          J[r * ld + rolecol[IMU_ROLE_POSE] + 6 * i + 3 + c] = f * (w0 * Q0[3 * r + c] + w1 * Q1[3 * r + c] + w2 * Q2[3 * r + c]);
+        }
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // F2: ReprojectionError with camera design variables over a static chain
 //   p_c = B_{n-1} * ... * B_0 * inverse(T_t_c) * p      (CameraCalibrator.py:195-212)
 // roles: 0 q_t_c, 1 t_t_c, 2+2j / 3+2j = q / t of baseline j (j < 4), 10 projection, 11 distortion

@@ -10,7 +10,7 @@ object that offers the C-ABI call surface (the HIP backend here; the CPU oracle 
 import numpy as np
 
 DV_EUCLIDEAN_POINT, DV_ROTATION_QUATERNION, DV_SCALAR, DV_EUCLIDEAN_DIRECTION = 0, 1, 2, 3
-DV_SPLINE_COEFF, DV_PROJECTION, DV_DISTORTION = 4, 5, 6
+DV_SPLINE_COEFF, DV_PROJECTION, DV_DISTORTION, DV_MATRIX_BASIC = 4, 5, 6, 7
 PROJ_PINHOLE, PROJ_OMNI, PROJ_DS = 0, 1, 2
 DIST_NONE, DIST_RADTAN, DIST_EQUI = 0, 1, 2
 MEST_NONE, MEST_HUBER, MEST_CAUCHY, MEST_GEMAN_MCCLURE, MEST_BZ, MEST_BLAKE_ZISSERMAN = range(6)
@@ -43,6 +43,12 @@ class ProblemSpec(object):
     def add_dv(self, kind, params, active=True, scaling=1.0, group=HELPER_GROUP_ID):
         self.ops.append(("dv", dict(kind=kind, params=_f64(params).ravel().copy(), active=bool(active),
                                     scaling=float(scaling), group=group)))
+        return len(self.ops) - 1
+
+    def add_matrix_dv(self, A, pattern, active=True, scaling=1.0, group=HELPER_GROUP_ID):
+        """aopt.MatrixBasicDv(A, updatePattern) (sensors_and_targets.py:1435-1447)"""
+        self.ops.append(("dv", dict(kind=DV_MATRIX_BASIC, params=_f64(A).reshape(9).copy(), pattern=_i32(pattern).reshape(9).copy(),
+                                    active=bool(active), scaling=float(scaling), group=group)))
         return len(self.ops) - 1
 
     def add_spline(self, order, knots, coeffs, active=True, group=HELPER_GROUP_ID):
@@ -83,6 +89,22 @@ class ProblemSpec(object):
         self.ops.append(("gyro", dict(pose_spline=pose_spline, bias_spline=bias_spline, dv_bias=dv_bias, dv_q_ib=dv_q_ib,
                                       t=_f64(t), meas=_f64(meas).reshape(-1, 3), sinv=_f64(sinv), mest=mest,
                                       mest_param=float(mest_param))))
+        return len(self.ops) - 1
+
+    def add_accelerometer_batch_sm(self, pose_spline, bias_spline, dv_bias, dv_gravity, dv_q_ib, dv_r_b, dv_M, size_effect, t, meas,
+                                   sinv, mest=MEST_NONE, mest_param=0.0):
+        """size_effect: None or the handles (rx_i, ry_i, rz_i, Ix, Iy, Iz)"""
+        self.ops.append(("accel_sm", dict(pose_spline=pose_spline, bias_spline=bias_spline, dv_bias=dv_bias, dv_gravity=dv_gravity,
+                                          dv_q_ib=dv_q_ib, dv_r_b=dv_r_b, dv_M=dv_M,
+                                          size_effect=None if size_effect is None else list(size_effect), t=_f64(t),
+                                          meas=_f64(meas).reshape(-1, 3), sinv=_f64(sinv), mest=mest, mest_param=float(mest_param))))
+        return len(self.ops) - 1
+
+    def add_gyroscope_batch_sm(self, pose_spline, bias_spline, dv_bias, dv_q_ib, dv_q_gi, dv_M, dv_Ma, dv_gravity, dv_r_b, t, meas,
+                               sinv, mest=MEST_NONE, mest_param=0.0):
+        self.ops.append(("gyro_sm", dict(pose_spline=pose_spline, bias_spline=bias_spline, dv_bias=dv_bias, dv_q_ib=dv_q_ib,
+                                         dv_q_gi=dv_q_gi, dv_M=dv_M, dv_Ma=dv_Ma, dv_gravity=dv_gravity, dv_r_b=dv_r_b, t=_f64(t),
+                                         meas=_f64(meas).reshape(-1, 3), sinv=_f64(sinv), mest=mest, mest_param=float(mest_param))))
         return len(self.ops) - 1
 
     def add_lidar_batch(self, spline, dv_toff, dv_q_lb, dv_t_lb, t, direction, rng, sinv, dv_q_pw, dv_t_pw, pad,
@@ -127,7 +149,9 @@ class ProblemSpec(object):
 
         for i in self.dv_order():
             k, d = self.ops[i]
-            if k == "dv":
+            if k == "dv" and d["kind"] == DV_MATRIX_BASIC:
+                ids[i] = api.add_matrix_design_variable(d["params"], d["pattern"], d["active"], d["scaling"])
+            elif k == "dv":
                 ids[i] = api.add_design_variable(d["kind"], d["params"], d["active"], d["scaling"])
             else:
                 ids[i] = ("spline", api.add_spline(d["order"], d["dim"], d["knots"], d["coeffs"], d["active"]))
@@ -154,6 +178,15 @@ class ProblemSpec(object):
             elif k == "gyro":
                 api.add_gyroscope_batch(sid(d["pose_spline"]), sid(d["bias_spline"]), dvid(d["dv_bias"]), dvid(d["dv_q_ib"]),
                                         d["t"], d["meas"], d["sinv"], d["mest"], d["mest_param"])
+            elif k == "accel_sm":
+                se = None if d["size_effect"] is None else _i32([dvid(h) for h in d["size_effect"]])
+                api.add_accelerometer_batch_sm(sid(d["pose_spline"]), sid(d["bias_spline"]), dvid(d["dv_bias"]),
+                                               dvid(d["dv_gravity"]), dvid(d["dv_q_ib"]), dvid(d["dv_r_b"]), dvid(d["dv_M"]), se,
+                                               d["t"], d["meas"], d["sinv"], d["mest"], d["mest_param"])
+            elif k == "gyro_sm":
+                api.add_gyroscope_batch_sm(sid(d["pose_spline"]), sid(d["bias_spline"]), dvid(d["dv_bias"]), dvid(d["dv_q_ib"]),
+                                           dvid(d["dv_q_gi"]), dvid(d["dv_M"]), dvid(d["dv_Ma"]), dvid(d["dv_gravity"]),
+                                           dvid(d["dv_r_b"]), d["t"], d["meas"], d["sinv"], d["mest"], d["mest_param"])
             elif k == "lidar":
                 api.add_lidar_batch(sid(d["spline"]), dvid(d["dv_toff"]), dvid(d["dv_q_lb"]), dvid(d["dv_t_lb"]), d["t"],
                                     d["dir"], d["range"], d["sinv"], _i32([dvid(h) for h in d["dv_q_pw"]]),

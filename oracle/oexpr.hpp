@@ -112,6 +112,36 @@ struct ParamVectorDv : DesignVariable {
   void getParameters(std::vector<double>& o) const override { o = p; }
 };
 
+// ABE/src/MatrixBasic.cpp:10-77: 3x3 matrix; _B (9 x n) selects the entries flagged in the update pattern, column k
+// of _B being the k-th flagged entry in the row-major scan of the pattern, at row col*3+row of the column-major vec(A)
+struct MatrixBasic : DesignVariable {
+  Mat A, pA, B;
+  MatrixBasic(const double* a /* row major */, const int* pattern /* row major */) : A(3, 3), pA(3, 3) {
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A(r, c) = pA(r, c) = a[3 * r + c];
+    int n = 0;
+    for (int i = 0; i < 9; ++i) if (pattern[i] != 0) ++n;
+    B = Mat(9, n);
+    int k = 0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        if (pattern[3 * r + c] != 0) { B(c * 3 + r, k) = 1.0; ++k; }
+  }
+  int minimalDimensions() const override { return B.c; }
+  void update(const double* dp) override {
+    pA = A;
+    for (int i = 0; i < 9; ++i) {       // dV = B d, A += unvec(dV) (column major)
+      double dv = 0.0;
+      for (int k = 0; k < B.c; ++k) dv += B(i, k) * dp[k];
+      A(i % 3, i / 3) += dv;
+    }
+  }
+  void revertUpdate() override { A = pA; }
+  void getParameters(std::vector<double>& o) const override {
+    o.clear();
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o.push_back(A(r, c));   // row major, like the product reports
+  }
+};
+
 // ---------------------------------------------------------------- JacobianContainer
 // AB/include/aslam/backend/JacobianContainer.hpp:119-135, AB/src/JacobianContainer.cpp.
 // Keyed by design variable, ordered by block index; inactive variables are dropped by add().
@@ -401,6 +431,24 @@ struct EuclideanTranslationNode : EuclideanNode {  // :416-446
     T->evalJ(jc, &c);
   }
   void getDvs(std::set<DesignVariable*>& s) override { T->getDvs(s); }
+};
+
+// MatrixBasic as an expression leaf + EuclideanExpressionNodeMatrixMultiply (ABE/src/EuclideanExpressionNode.cpp:91-134)
+struct EuclideanMatrixMultiplyNode : EuclideanNode {
+  MatrixBasic* M;
+  EucP r;
+  Mat Al, pr;
+  EuclideanMatrixMultiplyNode(MatrixBasic* m, EucP r_) : M(m), r(r_) {}
+  Mat toEuclidean() override { Al = M->A; pr = r->toEuclidean(); return Al * pr; }
+  void evalJ(JacobianContainer& jc, const Mat* chain) override {
+    Mat Jfull(3, 9);
+    for (int c = 0; c < 3; ++c) for (int d = 0; d < 3; ++d) Jfull(d, 3 * c + d) = pr[c];   // [p0 I, p1 I, p2 I]
+    // MatrixBasic::evaluateJacobiansImplementation(chain): add(this, chain * _B) if minimalDimensions != 0
+    if (M->minimalDimensions() != 0) jc.add(M, chainOr(chain, Jfull) * M->B);
+    Mat c2 = chainOr(chain, Al);
+    r->evalJ(jc, &c2);
+  }
+  void getDvs(std::set<DesignVariable*>& s) override { if (M->minimalDimensions() != 0) s.insert(M); r->getDvs(s); }
 };
 
 // --- scalar nodes (ABE/src/ScalarExpressionNode.cpp)

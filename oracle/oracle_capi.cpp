@@ -11,7 +11,7 @@ using namespace orc;
 namespace {
 
 enum { DV_EUCLIDEAN_POINT = 0, DV_ROTATION_QUATERNION = 1, DV_SCALAR = 2, DV_EUCLIDEAN_DIRECTION = 3,
-       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6 };
+       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6, DV_MATRIX_BASIC = 7 };
 
 struct Problem {
   std::vector<std::unique_ptr<DesignVariable>> ownedDvs;
@@ -72,6 +72,20 @@ int orc_add_dv(void* h, int kind, const double* params, int n, int active, doubl
   P->ownedDvs.emplace_back(d);
   P->dvs.push_back(d);
   P->dvKind.push_back(kind);
+  return d->id;
+  ORC_CATCH(P, -1)
+}
+
+int orc_add_matrix_dv(void* h, const double* A, const int* pattern, int active, double scaling) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  MatrixBasic* d = new MatrixBasic(A, pattern);
+  d->active = active != 0 && d->minimalDimensions() > 0;
+  d->scaling = scaling;
+  d->id = (int)P->dvs.size();
+  P->ownedDvs.emplace_back(d);
+  P->dvs.push_back(d);
+  P->dvKind.push_back(DV_MATRIX_BASIC);
   return d->id;
   ORC_CATCH(P, -1)
 }
@@ -211,6 +225,100 @@ int orc_add_gyro_batch(void* h, int poseSpline, int biasSpline, int dvBias, int 
     EucP w_b(new SplineAngularRateBodyNode(ps, tk, 1));
     EucP b_i = biasExpr(P, biasSpline, dvBias, tk);
     EucP w(new EuclideanRotateNode(C_i_b, w_b));
+    EucP pred(new EuclideanAddNode(w, b_i));
+    std::unique_ptr<EuclideanError> e(new EuclideanError(&meas[3 * k], sinv[k], pred));
+    e->mest.kind = mestKind; e->mest.a = mestParam;
+    P->terms.push_back(std::move(e));
+  }
+  return 0;
+  ORC_CATCH(P, -1)
+}
+
+static EucP gravityExpr(Problem* P, int dvGravity) {
+  if (P->dvKind[dvGravity] == DV_EUCLIDEAN_DIRECTION) return EucP(new EuclideanDirectionNode(P->dvAs<EuclideanDirection>(dvGravity)));
+  return EucP(new EuclideanPointNode(P->dvAs<EuclideanPoint>(dvGravity)));
+}
+static EucP leverTerms(EucP w_dot_b, EucP w_b, EucP r) {   // w_dot_b.cross(r) + w_b.cross(w_b.cross(r))
+  EucP t2(new EuclideanCrossNode(w_dot_b, r));
+  EucP t3(new EuclideanCrossNode(w_b, EucP(new EuclideanCrossNode(w_b, r))));
+  return EucP(new EuclideanAddNode(t2, t3));
+}
+
+// F3, ScaledMisalignedImu.addAccelerometerErrorTerms (sensors_and_targets.py:1449-1497) and, with sizeEffect != NULL
+// (rx_i, ry_i, rz_i, Ix, Iy, Iz), ScaledMisalignedSizeEffectImu.addAccelerometerErrorTerms (:1608-1661)
+int orc_add_accel_sm_batch(void* h, int poseSpline, int biasSpline, int dvBias, int dvGravity, int dvQib, int dvRb, int dvM,
+                           const int* sizeEffect, int n, const double* t, const double* meas, const double* sinv, int mestKind,
+                           double mestParam) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  SplineDv* ps = P->splines[poseSpline].get();
+  EucP g_w = gravityExpr(P, dvGravity);
+  RotP C_i_b(new RotationQuaternionNode(P->dvAs<RotationQuaternion>(dvQib)));
+  EucP r_b(new EuclideanPointNode(P->dvAs<EuclideanPoint>(dvRb)));
+  MatrixBasic* M = P->dvAs<MatrixBasic>(dvM);
+  for (int k = 0; k < n; ++k) {
+    double tk = t[k];
+    RotP C_b_w(new RotationInverseNode(RotP(new SplineRotationNode(ps, tk))));
+    EucP a_w(new SplineEuclideanDerivNode(ps, tk, 2));
+    EucP b_i = biasExpr(P, biasSpline, dvBias, tk);
+    EucP w_b(new SplineAngularRateBodyNode(ps, tk, 1));
+    EucP w_dot_b(new SplineAngularRateBodyNode(ps, tk, 2));
+    EucP t1(new EuclideanRotateNode(C_b_w, EucP(new EuclideanSubtractNode(a_w, g_w))));
+    EucP a;
+    if (!sizeEffect) {
+      // a = M * (C_i_b * (C_b_w * (a_w - g_w) + w_dot_b.cross(r_b) + w_b.cross(w_b.cross(r_b))))
+      EucP t2(new EuclideanCrossNode(w_dot_b, r_b));
+      EucP t3(new EuclideanCrossNode(w_b, EucP(new EuclideanCrossNode(w_b, r_b))));
+      EucP inner(new EuclideanAddNode(EucP(new EuclideanAddNode(t1, t2)), t3));
+      a.reset(new EuclideanMatrixMultiplyNode(M, EucP(new EuclideanRotateNode(C_i_b, inner))));
+    } else {
+      // rx_b = r_b + C_i_b.inverse() * rx_i ;  a = M * (C_i_b * t1 + Ix * (C_i_b * (...rx_b...)) + Iy * (...) + Iz * (...))
+      EucP sum(new EuclideanRotateNode(C_i_b, t1));
+      for (int j = 0; j < 3; ++j) {
+        EucP rj_i(new EuclideanPointNode(P->dvAs<EuclideanPoint>(sizeEffect[j])));
+        EucP rj_b(new EuclideanAddNode(r_b, EucP(new EuclideanRotateNode(RotP(new RotationInverseNode(C_i_b)), rj_i))));
+        EucP sj(new EuclideanRotateNode(C_i_b, leverTerms(w_dot_b, w_b, rj_b)));
+        sum.reset(new EuclideanAddNode(sum, EucP(new EuclideanMatrixMultiplyNode(P->dvAs<MatrixBasic>(sizeEffect[3 + j]), sj))));
+      }
+      a.reset(new EuclideanMatrixMultiplyNode(M, sum));
+    }
+    EucP pred(new EuclideanAddNode(a, b_i));
+    std::unique_ptr<EuclideanError> e(new EuclideanError(&meas[3 * k], sinv[k], pred));
+    e->mest.kind = mestKind; e->mest.a = mestParam;
+    P->terms.push_back(std::move(e));
+  }
+  return 0;
+  ORC_CATCH(P, -1)
+}
+
+// F4, ScaledMisalignedImu.addGyroscopeErrorTerms (sensors_and_targets.py:1499-1550)
+int orc_add_gyro_sm_batch(void* h, int poseSpline, int biasSpline, int dvBias, int dvQib, int dvQgi, int dvM, int dvMa, int dvGravity,
+                          int dvRb, int n, const double* t, const double* meas, const double* sinv, int mestKind, double mestParam) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  SplineDv* ps = P->splines[poseSpline].get();
+  EucP g_w = gravityExpr(P, dvGravity);
+  RotP C_i_b(new RotationQuaternionNode(P->dvAs<RotationQuaternion>(dvQib)));
+  RotP C_gyro_i(new RotationQuaternionNode(P->dvAs<RotationQuaternion>(dvQgi)));
+  EucP r_b(new EuclideanPointNode(P->dvAs<EuclideanPoint>(dvRb)));
+  MatrixBasic* M = P->dvAs<MatrixBasic>(dvM);
+  MatrixBasic* Ma = P->dvAs<MatrixBasic>(dvMa);
+  for (int k = 0; k < n; ++k) {
+    double tk = t[k];
+    EucP w_b(new SplineAngularRateBodyNode(ps, tk, 1));
+    EucP w_dot_b(new SplineAngularRateBodyNode(ps, tk, 2));
+    EucP b_i = biasExpr(P, biasSpline, dvBias, tk);
+    RotP C_b_w(new RotationInverseNode(RotP(new SplineRotationNode(ps, tk))));
+    EucP a_w(new SplineEuclideanDerivNode(ps, tk, 2));
+    // a_b = C_b_w * (a_w - g_w) + w_dot_b.cross(r_b) + w_b.cross(w_b.cross(r_b))
+    EucP t1(new EuclideanRotateNode(C_b_w, EucP(new EuclideanSubtractNode(a_w, g_w))));
+    EucP t2(new EuclideanCrossNode(w_dot_b, r_b));
+    EucP t3(new EuclideanCrossNode(w_b, EucP(new EuclideanCrossNode(w_b, r_b))));
+    EucP a_b(new EuclideanAddNode(EucP(new EuclideanAddNode(t1, t2)), t3));
+    RotP C_gyro_b(new RotationMultiplyNode(C_gyro_i, C_i_b));
+    // w = M * (C_gyro_b * w_b) + Ma * (C_gyro_b * a_b)
+    EucP w(new EuclideanAddNode(EucP(new EuclideanMatrixMultiplyNode(M, EucP(new EuclideanRotateNode(C_gyro_b, w_b)))),
+                                EucP(new EuclideanMatrixMultiplyNode(Ma, EucP(new EuclideanRotateNode(C_gyro_b, a_b))))));
     EucP pred(new EuclideanAddNode(w, b_i));
     std::unique_ptr<EuclideanError> e(new EuclideanError(&meas[3 * k], sinv[k], pred));
     e->mest.kind = mestKind; e->mest.a = mestParam;

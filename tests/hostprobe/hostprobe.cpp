@@ -53,6 +53,17 @@ int probe_add_accelerometer_batch(void* h, int ps, int bs, int db, int dg, int d
 int probe_add_gyroscope_batch(void* h, int ps, int bs, int db, int dq, int n, const double* t, const double* me, const double* s, int m, double ma) {
   Probe* pr = (Probe*)h; PR_TRY describeImu(pr->P, false, ps, bs, db, -1, dq, -1, n, t, me, s, m, ma); return 0; PR_CATCH(pr, -1)
 }
+int probe_add_matrix_design_variable(void* h, const double* A, const int* pat, int active, double scaling) {
+  Probe* pr = (Probe*)h; PR_TRY return pr->P.addMatrixDv(A, pat, active, scaling); PR_CATCH(pr, -1)
+}
+int probe_add_accelerometer_batch_sm(void* h, int ps, int bs, int db, int dg, int dq, int dr, int dM, const int* se, int n, const double* t,
+                                     const double* me, const double* s, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeImuSm(pr->P, true, ps, bs, db, dg, dq, dr, dM, -1, -1, se, n, t, me, s, m, ma); return 0; PR_CATCH(pr, -1)
+}
+int probe_add_gyroscope_batch_sm(void* h, int ps, int bs, int db, int dq, int dqg, int dM, int dMa, int dg, int dr, int n, const double* t,
+                                 const double* me, const double* s, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeImuSm(pr->P, false, ps, bs, db, dg, dq, dr, dM, dqg, dMa, nullptr, n, t, me, s, m, ma); return 0; PR_CATCH(pr, -1)
+}
 int probe_add_lidar_batch(void* h, int sp, int dtoff, int dq, int dt, int n, const double* t, const double* dir, const double* rg,
                           const double* s, const int* q, const int* tv, double pad, int m, double ma) {
   Probe* pr = (Probe*)h; PR_TRY describeLidar(pr->P, sp, dtoff, dq, dt, n, t, dir, rg, s, q, tv, pad, m, ma); return 0; PR_CATCH(pr, -1)
@@ -176,6 +187,27 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     else rolecol[IMU_ROLE_BIAS] = v.bias_dv.col;
     rolecol[IMU_ROLE_G] = v.g.col; rolecol[IMU_ROLE_QIB] = v.q_ib.col; rolecol[IMU_ROLE_RB] = v.r_b.col;
     if (!imu_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out)) throw std::runtime_error("time out of spline");
+  } else if (B.kind == KIND_ACCEL_SM || B.kind == KIND_GYRO_SM) {
+    ImuSmBatchView v;
+    v.pose = P.splineView(B.spline, P.knots.data(), P.basis.data());
+    v.bias = P.splineView(B.bias_spline, P.knots.data(), P.basis.data());
+    v.bias_dv = P.dvRef(B.dv[0]); v.g = P.dvRef(B.dv[1]); v.q_ib = P.dvRef(B.dv[2]); v.r_b = P.dvRef(B.dv[3]);
+    v.g_is_direction = P.dvs[B.dv[1]].kind == DV_EUCLIDEAN_DIRECTION ? 1 : 0;
+    v.pose_scale = 1.0; v.bias_scale = B.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
+    v.t = B.t.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    v.is_accel = B.kind == KIND_ACCEL_SM;
+    v.M = P.dvRef(B.dv[4]); v.M_mask = P.dvs[B.dv[4]].mask;
+    v.q_gi = P.dvRef(B.dv[5]); v.Ma = P.dvRef(B.dv[6]); v.Ma_mask = B.dv[6] >= 0 ? P.dvs[B.dv[6]].mask : 0;
+    v.size_effect = B.size_effect;
+    for (int j = 0; j < 3; ++j) { v.arm[j] = P.dvRef(B.dv[7 + j]); v.I_off[j] = B.dv[10 + j] >= 0 ? P.dvs[B.dv[10 + j]].off : -1; }
+    int seg = spline_segment(v.pose, B.t[k]);
+    rolecol[IMU_ROLE_POSE] = v.pose.first_col >= 0 ? v.pose.first_col + 6 * seg : -1;
+    if (B.bias_spline >= 0) { int bs = spline_segment(v.bias, B.t[k]); rolecol[IMU_ROLE_BIAS] = v.bias.first_col >= 0 ? v.bias.first_col + 3 * bs : -1; }
+    else rolecol[IMU_ROLE_BIAS] = v.bias_dv.col;
+    rolecol[IMU_ROLE_G] = v.g.col; rolecol[IMU_ROLE_QIB] = v.q_ib.col; rolecol[IMU_ROLE_RB] = v.r_b.col;
+    rolecol[IMU_ROLE_M] = v.M.col; rolecol[IMU_ROLE_QGI] = v.q_gi.col; rolecol[IMU_ROLE_MA] = v.Ma.col;
+    for (int j = 0; j < 3; ++j) rolecol[IMU_ROLE_RX + j] = v.arm[j].col;
+    if (!imu_sm_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out)) throw std::runtime_error("time out of spline");
   } else if (B.kind == KIND_STATIC_REPROJ) {
     StaticReprojBatchView v;
     v.cam = P.cameraView(B.cam);

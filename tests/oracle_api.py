@@ -120,6 +120,26 @@ class OracleApi(object):
                                               C.c_int(dv_q_ib), C.c_int(t.size), _d(t), _d(meas), _d(sinv), C.c_int(mest),
                                               C.c_double(mest_param)))
 
+    def add_matrix_design_variable(self, A, pattern, active=True, scaling=1.0):
+        A, pattern = _f64(A).reshape(9), _i32(pattern).reshape(9)
+        return self._chk(self.lib.orc_add_matrix_dv(self.h, _d(A), _i(pattern), C.c_int(int(bool(active))), C.c_double(scaling)))
+
+    def add_accelerometer_batch_sm(self, pose_spline, bias_spline, dv_bias, dv_g, dv_q_ib, dv_r_b, dv_M, size_effect, t, meas, sinv,
+                                   mest=0, mest_param=0.0):
+        t, meas, sinv = _f64(t), _f64(meas), _f64(sinv)
+        se = None if size_effect is None else _i32(size_effect)
+        self._chk(self.lib.orc_add_accel_sm_batch(self.h, C.c_int(pose_spline), C.c_int(bias_spline), C.c_int(dv_bias), C.c_int(dv_g),
+                                                  C.c_int(dv_q_ib), C.c_int(dv_r_b), C.c_int(dv_M), None if se is None else _i(se),
+                                                  C.c_int(t.size), _d(t), _d(meas), _d(sinv), C.c_int(mest), C.c_double(mest_param)))
+
+    def add_gyroscope_batch_sm(self, pose_spline, bias_spline, dv_bias, dv_q_ib, dv_q_gi, dv_M, dv_Ma, dv_g, dv_r_b, t, meas, sinv,
+                               mest=0, mest_param=0.0):
+        t, meas, sinv = _f64(t), _f64(meas), _f64(sinv)
+        self._chk(self.lib.orc_add_gyro_sm_batch(self.h, C.c_int(pose_spline), C.c_int(bias_spline), C.c_int(dv_bias),
+                                                 C.c_int(dv_q_ib), C.c_int(dv_q_gi), C.c_int(dv_M), C.c_int(dv_Ma), C.c_int(dv_g),
+                                                 C.c_int(dv_r_b), C.c_int(t.size), _d(t), _d(meas), _d(sinv), C.c_int(mest),
+                                                 C.c_double(mest_param)))
+
     def add_lidar_batch(self, spline, dv_toff, dv_q_lb, dv_t_lb, t, direction, rng, sinv, dv_q_pw, dv_t_pw, pad, mest=0,
                         mest_param=0.0):
         t, direction, rng, sinv = _f64(t), _f64(direction), _f64(rng), _f64(sinv)

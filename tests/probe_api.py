@@ -80,6 +80,24 @@ class ProbeApi(object):
         self._chk(self.L.probe_add_gyroscope_batch(self.h, C.c_int(ps), C.c_int(bs), C.c_int(db), C.c_int(dq), C.c_int(t.size), _d(t),
                                                    _d(me), _d(s), C.c_int(m), C.c_double(ma)))
 
+    def add_matrix_design_variable(self, A, pattern, active=True, scaling=1.0):
+        A, pattern = _f64(A).reshape(9), _i32(pattern).reshape(9)
+        return self._chk(self.L.probe_add_matrix_design_variable(self.h, _d(A), _i(pattern), C.c_int(int(bool(active))),
+                                                                 C.c_double(scaling)))
+
+    def add_accelerometer_batch_sm(self, ps, bs, db, dg, dq, dr, dM, se, t, me, s, m=0, ma=0.0):
+        t, me, s = _f64(t), _f64(me), _f64(s)
+        se = None if se is None else _i32(se)
+        self._chk(self.L.probe_add_accelerometer_batch_sm(self.h, C.c_int(ps), C.c_int(bs), C.c_int(db), C.c_int(dg), C.c_int(dq),
+                                                          C.c_int(dr), C.c_int(dM), None if se is None else _i(se), C.c_int(t.size),
+                                                          _d(t), _d(me), _d(s), C.c_int(m), C.c_double(ma)))
+
+    def add_gyroscope_batch_sm(self, ps, bs, db, dq, dqg, dM, dMa, dg, dr, t, me, s, m=0, ma=0.0):
+        t, me, s = _f64(t), _f64(me), _f64(s)
+        self._chk(self.L.probe_add_gyroscope_batch_sm(self.h, C.c_int(ps), C.c_int(bs), C.c_int(db), C.c_int(dq), C.c_int(dqg),
+                                                      C.c_int(dM), C.c_int(dMa), C.c_int(dg), C.c_int(dr), C.c_int(t.size), _d(t),
+                                                      _d(me), _d(s), C.c_int(m), C.c_double(ma)))
+
     def add_lidar_batch(self, sp, dtoff, dq, dt, t, dr, rg, s, q, tv, pad, m=0, ma=0.0):
         t, dr, rg, s = _f64(t), _f64(dr), _f64(rg), _f64(s)
         q, tv = _i32(q), _i32(tv)

@@ -8,6 +8,9 @@ ABI against the oracle (1e-9).  Variants of the small Multical problem:
   all_mestimators       Cauchy, Geman-McClure, Huber and "bz" spread over the batches
   unsorted_streams      LiDAR and IMU samples handed over in shuffled time order
   ragged                observations cut down to 1..3 corners, one LiDAR batch emptied to a single point
+  scale_misalignment    every IMU modelled as ScaledMisalignedImu (--imu-models scale-misalignment): MatrixBasic design
+                        variables M_accel / M_gyro / M_accel_gyro and the gyroscope axis rotation q_gyro_i
+  size_effect           ScaledMisalignedSizeEffectImu: per-axis accelerometer lever arms on top of the above
 """
 import copy
 
@@ -17,7 +20,8 @@ import pytest
 from multical_amd import spec as S
 
 RTOL = 1e-9
-VARIANTS = ["no_time_calibration", "pose_fixed", "static_bias_point_g", "all_mestimators", "unsorted_streams", "ragged"]
+VARIANTS = ["no_time_calibration", "pose_fixed", "static_bias_point_g", "all_mestimators", "unsorted_streams", "ragged",
+            "scale_misalignment", "size_effect"]
 
 
 def make_variant(spec, name):
@@ -77,6 +81,37 @@ def make_variant(spec, name):
             for f in ("t", "dir", "range", "sinv"):
                 d[f] = d[f][:1]
             d["dv_q_pw"], d["dv_t_pw"] = d["dv_q_pw"][:1], d["dv_t_pw"][:1]
+    elif name in ("scale_misalignment", "size_effect"):
+        # sensors_and_targets.py:1428-1447, 1583-1606: the extra design variables of the two models, at values away from
+        # their identity / zero initial guesses so that every chain carries signal
+        lower, full, none = np.tril(np.ones((3, 3), int)), np.ones((3, 3), int), np.zeros((3, 3), int)
+        accel_of = {d["dv_q_ib"]: d for _, k, d in sp.batch_ops() if k == "accel"}
+        extra = {}
+        for q_ib, da in accel_of.items():
+            ax = rng.standard_normal(3) * 0.05
+            q = np.concatenate([np.sin(0.5 * np.linalg.norm(ax)) * ax / np.linalg.norm(ax), [np.cos(0.5 * np.linalg.norm(ax))]])
+            ex = dict(q_gi=sp.add_dv(S.DV_ROTATION_QUATERNION, q),
+                      M_a=sp.add_matrix_dv(np.eye(3) + 0.05 * np.tril(rng.standard_normal((3, 3))), lower),
+                      M_g=sp.add_matrix_dv(np.eye(3) + 0.05 * np.tril(rng.standard_normal((3, 3))), lower),
+                      M_ag=sp.add_matrix_dv(0.01 * rng.standard_normal((3, 3)), full))
+            if name == "size_effect":
+                ex["arms"] = [sp.add_dv(S.DV_EUCLIDEAN_POINT, 0.02 * rng.standard_normal(3), active=(j > 0)) for j in range(3)]
+                ex["sel"] = [sp.add_matrix_dv(np.diag(np.eye(3)[j]), none, active=False) for j in range(3)]
+            extra[q_ib] = ex
+        for i, (k, d) in enumerate(sp.ops):
+            if k == "accel":
+                ex = extra[d["dv_q_ib"]]
+                se = ex["arms"] + ex["sel"] if name == "size_effect" else None
+                sp.ops[i] = ("accel_sm", dict(pose_spline=d["pose_spline"], bias_spline=d["bias_spline"], dv_bias=d["dv_bias"],
+                                              dv_gravity=d["dv_gravity"], dv_q_ib=d["dv_q_ib"], dv_r_b=d["dv_r_b"], dv_M=ex["M_a"],
+                                              size_effect=se, t=d["t"], meas=d["meas"], sinv=d["sinv"], mest=d["mest"],
+                                              mest_param=d["mest_param"]))
+            elif k == "gyro":
+                ex, da = extra[d["dv_q_ib"]], accel_of[d["dv_q_ib"]]
+                sp.ops[i] = ("gyro_sm", dict(pose_spline=d["pose_spline"], bias_spline=d["bias_spline"], dv_bias=d["dv_bias"],
+                                             dv_q_ib=d["dv_q_ib"], dv_q_gi=ex["q_gi"], dv_M=ex["M_g"], dv_Ma=ex["M_ag"],
+                                             dv_gravity=da["dv_gravity"], dv_r_b=da["dv_r_b"], t=d["t"], meas=d["meas"],
+                                             sinv=d["sinv"], mest=d["mest"], mest_param=d["mest_param"]))
     else:
         raise KeyError(name)
     return sp
@@ -140,6 +175,23 @@ def test_variant_product_math_matches_oracle(variants, name):
     assert wj < RTOL and we < RTOL and wc < RTOL, (wj, we, wc)
 
 
+@pytest.mark.parametrize("name", ["scale_misalignment", "size_effect"])
+def test_imu_model_oracle_jacobians_match_finite_differences(variants, name):
+    """The oracle's DAG for the two other IMU models against central differences through update / revertUpdate
+    (ErrorTermTestHarness.hpp:20-35; the reference's own IMU error-term tests use 1e-5, kalibr/test/TestErrorTerms.cpp),
+    which also exercises MatrixBasic::update (MatrixBasic.cpp:40-46)."""
+    from test_oracle_identities import _fd_check
+    sp, o = variants[name]
+    terms, base = [], 0
+    for _, k, d in sp.batch_ops():
+        n = 1 if k == "motion" else len(d["sinv"])
+        if k in ("accel_sm", "gyro_sm"):
+            terms += [base + 1, base + n // 2]
+        base += n
+    assert terms
+    _fd_check(o, terms, 1e-6)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", VARIANTS)
 def test_variant_gpu_parity(variants, name):
@@ -183,24 +235,26 @@ def _without_motion(sp):
         for f, v in list(d.items()):
             if isinstance(v, (int, np.integer)) and not isinstance(v, bool) and (f in ("camera", "spline", "pose_spline", "bias_spline", "dv_proj", "dv_dist") or f.startswith("dv_")):
                 d[f] = rm(int(v))
-            elif isinstance(v, list) and (f.startswith("obs_dv") or f.startswith("dv_") or f.startswith("chain_dv")):
+            elif isinstance(v, list) and (f.startswith("obs_dv") or f.startswith("dv_") or f.startswith("chain_dv") or f == "size_effect"):
                 d[f] = [rm(h) for h in v]
     out.ops = ops
     return out
 
 
 @pytest.mark.gpu
-def test_jacobian_transpose_backend_on_the_spline_problem(small_problem):
-    """J^T (SparseCholesky backend) for F1 / F3 / F4 / F5 with time-offset padding: bit-exact structure, values 1e-9;
-    with the BSplineMotionError terms in the problem the call is refused like in the reference."""
+@pytest.mark.parametrize("model", ["calibrated", "scale_misalignment", "size_effect"])
+def test_jacobian_transpose_backend_on_the_spline_problem(small_problem, model):
+    """J^T (SparseCholesky backend) for F1 / F3 / F4 / F5 with time-offset padding, for each IMU model: bit-exact
+    structure, values 1e-9; with the BSplineMotionError terms in the problem the call is refused like in the reference."""
     from multical_amd.backend import BackendError, HipApi
     from oracle_api import OracleApi
+    base = small_problem["spec"] if model == "calibrated" else make_variant(small_problem["spec"], model)
     g0 = HipApi(0)
-    small_problem["spec"].emit(g0)
+    base.emit(g0)
     g0.finalize()
     with pytest.raises(BackendError, match="unsupported"):
         g0.jt_pattern()
-    sp = _without_motion(small_problem["spec"])
+    sp = _without_motion(base)
     o = OracleApi()
     sp.emit(o)
     o.finalize()
