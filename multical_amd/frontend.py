@@ -102,6 +102,22 @@ class EuclideanDirection(DesignVariable):
         return EuclideanExpression(("e_leaf", self))
 
 
+class MatrixBasicDv(DesignVariable):
+    """aopt.MatrixBasicDv(A, updatePattern) (aslam_backend_expressions/src/MatrixBasic.cpp:10-47; used by the
+    scale-misalignment IMU models, sensors_and_targets.py:1435-1447, 1598-1606)."""
+    kind = S.DV_MATRIX_BASIC
+
+    def __init__(self, A, updatePattern=None):
+        DesignVariable.__init__(self, np.asarray(A, dtype=np.float64).reshape(3, 3))
+        self.pattern = (np.ones((3, 3), int) if updatePattern is None else np.asarray(updatePattern, dtype=int).reshape(3, 3)).ravel()
+
+    def toExpression(self):
+        return MatrixExpression(("m_leaf", self))
+
+    def toMatrix3x3(self):
+        return self.params.reshape(3, 3)
+
+
 class Scalar(DesignVariable):
     kind = S.DV_SCALAR
 
@@ -331,7 +347,20 @@ class EuclideanExpression(object):
             return np.cross(n[1].toEuclidean(), n[2].toEuclidean())
         if k == "e_bias_spline":
             return n[1].spline().eval(n[2], n[3])
+        if k == "e_mat_mul":
+            return n[1].toMatrix3x3() @ n[2].toEuclidean()
         raise NotImplementedError("numeric value of %s is not needed to build the problem" % k)
+
+
+class MatrixExpression(object):
+    def __init__(self, node):
+        self.node = node
+
+    def __mul__(self, o):
+        return EuclideanExpression(("e_mat_mul", self, o))
+
+    def toMatrix3x3(self):
+        return self.node[1].toMatrix3x3()
 
 
 class HomogeneousExpression(object):
@@ -664,6 +693,52 @@ def _match_gyro(term):
                 sinv=_isotropic(term.invR, "gyroscope error"))
 
 
+def _match_gravity_part(e):
+    """C_b_w(t) * (a_w(t) - g_w) -> (spline dv, t, gravity dv)"""
+    n = e.node
+    if n[0] != "e_rot_mul" or n[1].node[0] != "r_inv" or n[1].node[1].node[0] != "r_spline":
+        return None
+    sdv, t = n[1].node[1].node[1], n[1].node[1].node[2]
+    diff = n[2].node
+    if diff[0] != "e_sub" or _spline_e(diff[1], "lin_acc") != (sdv, t) or diff[2].node[0] != "e_leaf":
+        return None
+    return sdv, t, diff[2].node[1]
+
+
+def _match_lever(lever, centripetal, sdv, t, arm):
+    """w_dot_b x r  and  w_b x (w_b x r) over the same r; `arm(r_expression)` identifies r. Returns arm's result."""
+    lever, centripetal = lever.node, centripetal.node
+    if lever[0] != "e_cross" or _spline_e(lever[1], "ang_acc_b") != (sdv, t):
+        return None
+    if centripetal[0] != "e_cross" or _spline_e(centripetal[1], "ang_vel_b") != (sdv, t):
+        return None
+    c2 = centripetal[2].node
+    if c2[0] != "e_cross" or _spline_e(c2[1], "ang_vel_b") != (sdv, t):
+        return None
+    r1, r2 = arm(lever[2]), arm(c2[2])
+    if r1 is None or r2 is None or any(a is not b for a, b in zip(r1, r2)):
+        return None
+    return r1
+
+
+def _leaf_arm(e):
+    return (e.node[1],) if e.node[0] == "e_leaf" else None
+
+
+def _match_specific_force(e):
+    """C_b_w (a_w - g_w) + w_dot_b x r_b + w_b x (w_b x r_b) -> (spline dv, t, g, r_b)"""
+    inner = e.node
+    if inner[0] != "e_add" or inner[1].node[0] != "e_add":
+        return None
+    gp = _match_gravity_part(inner[1].node[1])
+    if gp is None:
+        return None
+    r = _match_lever(inner[1].node[2], inner[2], gp[0], gp[1], _leaf_arm)
+    if r is None:
+        return None
+    return gp[0], gp[1], gp[2], r[0]
+
+
 def _match_accel(term):
     """C_i_b * (C_b_w (a_w - g_w) + w_dot_b x r_b + w_b x (w_b x r_b)) + b_a(t)   (sensors_and_targets.py:1152-1170)"""
     n = term.predicted.node
@@ -672,29 +747,98 @@ def _match_accel(term):
     rm, bias = n[1].node, _match_bias(n[2])
     if bias is None or rm[0] != "e_rot_mul" or rm[1].node[0] != "r_leaf":
         return None
-    inner = rm[2].node
-    if inner[0] != "e_add" or inner[1].node[0] != "e_add":
+    sf = _match_specific_force(rm[2])
+    if sf is None or (bias[2] is not None and bias[2] != sf[1]):
         return None
-    grav_part, lever, centripetal = inner[1].node[1].node, inner[1].node[2].node, inner[2].node
-    if grav_part[0] != "e_rot_mul" or grav_part[1].node[0] != "r_inv" or grav_part[1].node[1].node[0] != "r_spline":
-        return None
-    sdv, t = grav_part[1].node[1].node[1], grav_part[1].node[1].node[2]
-    diff = grav_part[2].node
-    if diff[0] != "e_sub" or _spline_e(diff[1], "lin_acc") != (sdv, t) or diff[2].node[0] != "e_leaf":
-        return None
-    g = diff[2].node[1]
-    if lever[0] != "e_cross" or _spline_e(lever[1], "ang_acc_b") != (sdv, t) or lever[2].node[0] != "e_leaf":
-        return None
-    r_b = lever[2].node[1]
-    if centripetal[0] != "e_cross" or _spline_e(centripetal[1], "ang_vel_b") != (sdv, t):
-        return None
-    c2 = centripetal[2].node
-    if c2[0] != "e_cross" or _spline_e(c2[1], "ang_vel_b") != (sdv, t) or c2[2].node[0] != "e_leaf" or c2[2].node[1] is not r_b:
-        return None
-    if bias[2] is not None and bias[2] != t:
-        return None
-    return dict(spline=sdv, t=t, q_ib=rm[1].node[1], r_b=r_b, g=g, bias_spline=bias[0], bias_dv=bias[1], meas=term.meas,
+    return dict(spline=sf[0], t=sf[1], q_ib=rm[1].node[1], r_b=sf[3], g=sf[2], bias_spline=bias[0], bias_dv=bias[1], meas=term.meas,
                 sinv=_isotropic(term.invR, "accelerometer error"))
+
+
+def _mat_leaf(m):
+    return m.node[1] if isinstance(m, MatrixExpression) and m.node[0] == "m_leaf" else None
+
+
+def _match_accel_sm(term):
+    """ScaledMisalignedImu:            M * (C_i_b * (specific force at r_b)) + b_a           (sensors_and_targets.py:1482-1485)
+    ScaledMisalignedSizeEffectImu:  M * (C_i_b * (C_b_w (a_w - g_w)) + Ix * (C_i_b * lever(rx_b)) + Iy * (...) + Iz * (...)) + b_a,
+                                    rx_b = r_b + C_i_b.inverse() * rx_i                      (:1637-1649)"""
+    n = term.predicted.node
+    if n[0] != "e_add":
+        return None
+    mm, bias = n[1].node, _match_bias(n[2])
+    if bias is None or mm[0] != "e_mat_mul" or _mat_leaf(mm[1]) is None:
+        return None
+    M, body = _mat_leaf(mm[1]), mm[2].node
+    out = dict(M=M, bias_spline=bias[0], bias_dv=bias[1], meas=term.meas, sinv=_isotropic(term.invR, "accelerometer error"))
+    if body[0] == "e_rot_mul" and body[1].node[0] == "r_leaf":
+        sf = _match_specific_force(body[2])
+        if sf is None or (bias[2] is not None and bias[2] != sf[1]):
+            return None
+        out.update(spline=sf[0], t=sf[1], g=sf[2], r_b=sf[3], q_ib=body[1].node[1], size_effect=None)
+        return out
+    # size effect: ((grav + X) + Y) + Z
+    try:
+        z, y, x, grav = body[2].node, body[1].node[2].node, body[1].node[1].node[2].node, body[1].node[1].node[1].node
+    except (IndexError, AttributeError, TypeError):
+        return None
+    if body[0] != "e_add" or grav[0] != "e_rot_mul" or grav[1].node[0] != "r_leaf":
+        return None
+    q_ib = grav[1].node[1]
+    gp = _match_gravity_part(grav[2])
+    if gp is None or (bias[2] is not None and bias[2] != gp[1]):
+        return None
+    sdv, t, g = gp
+
+    def arm(e):      # r_b + C_i_b.inverse() * rx_i
+        a = e.node
+        if a[0] != "e_add" or a[1].node[0] != "e_leaf" or a[2].node[0] != "e_rot_mul":
+            return None
+        rot, leaf = a[2].node[1].node, a[2].node[2].node
+        if rot[0] != "r_inv" or rot[1].node[0] != "r_leaf" or rot[1].node[1] is not q_ib or leaf[0] != "e_leaf":
+            return None
+        return a[1].node[1], leaf[1]
+
+    arms, sels, r_b = [], [], None
+    for part in (x, y, z):
+        if part[0] != "e_mat_mul" or _mat_leaf(part[1]) is None:
+            return None
+        rot = part[2].node
+        if rot[0] != "e_rot_mul" or rot[1].node[0] != "r_leaf" or rot[1].node[1] is not q_ib or rot[2].node[0] != "e_add":
+            return None
+        r = _match_lever(rot[2].node[1], rot[2].node[2], sdv, t, arm)
+        if r is None or (r_b is not None and r[0] is not r_b):
+            return None
+        r_b = r[0]
+        arms.append(r[1]); sels.append(_mat_leaf(part[1]))
+    out.update(spline=sdv, t=t, g=g, r_b=r_b, q_ib=q_ib, size_effect=arms + sels)
+    return out
+
+
+def _match_gyro_sm(term):
+    """M * (C_gyro_b * w_b) + Ma * (C_gyro_b * a_b) + b_g,  C_gyro_b = C_gyro_i * C_i_b   (sensors_and_targets.py:1519-1538)"""
+    n = term.predicted.node
+    if n[0] != "e_add" or n[1].node[0] != "e_add":
+        return None
+    bias = _match_bias(n[2])
+    p1, p2 = n[1].node[1].node, n[1].node[2].node
+    if bias is None or p1[0] != "e_mat_mul" or p2[0] != "e_mat_mul" or _mat_leaf(p1[1]) is None or _mat_leaf(p2[1]) is None:
+        return None
+
+    def rot_chain(e):
+        r = e.node
+        if r[0] != "e_rot_mul" or r[1].node[0] != "r_mul":
+            return None
+        a, b = r[1].node[1].node, r[1].node[2].node
+        return (a[1], b[1], r[2]) if a[0] == "r_leaf" and b[0] == "r_leaf" else None
+
+    c1, c2 = rot_chain(p1[2]), rot_chain(p2[2])
+    if c1 is None or c2 is None or c1[0] is not c2[0] or c1[1] is not c2[1]:
+        return None
+    sf = _match_specific_force(c2[2])
+    if sf is None or _spline_e(c1[2], "ang_vel_b") != (sf[0], sf[1]) or (bias[2] is not None and bias[2] != sf[1]):
+        return None
+    return dict(spline=sf[0], t=sf[1], g=sf[2], r_b=sf[3], q_gi=c1[0], q_ib=c1[1], M=_mat_leaf(p1[1]), Ma=_mat_leaf(p2[1]),
+                bias_spline=bias[0], bias_dv=bias[1], meas=term.meas, sinv=_isotropic(term.invR, "gyroscope error"))
 
 
 def lower(problem):
@@ -706,6 +850,8 @@ def lower(problem):
         if isinstance(dv, _SplineDv):
             s = dv.spline()
             handles[id(dv)] = sp.add_spline(s.order, s.knots, s.coeffs, dv.active, group)
+        elif isinstance(dv, MatrixBasicDv):
+            handles[id(dv)] = sp.add_matrix_dv(dv.params, dv.pattern, dv.isActive(), dv.scaling, group)
         else:
             handles[id(dv)] = sp.add_dv(dv.kind, dv.params, dv.isActive(), dv.scaling, group)
 
@@ -717,6 +863,8 @@ def lower(problem):
             if isinstance(obj, _SplineDv):
                 s = obj.spline()
                 handles[id(obj)] = sp.add_spline(s.order, s.knots, s.coeffs, False, HELPER_GROUP_ID)
+            elif isinstance(obj, MatrixBasicDv):
+                handles[id(obj)] = sp.add_matrix_dv(obj.params, obj.pattern, False, obj.scaling, HELPER_GROUP_ID)
             else:
                 handles[id(obj)] = sp.add_dv(obj.kind, obj.params, False, obj.scaling, HELPER_GROUP_ID)
         return handles[id(obj)]
@@ -751,6 +899,14 @@ def lower(problem):
         elif kind == "gyro":
             sp.add_gyroscope_batch(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], np.array(run["t"]),
                                    np.array(run["meas"]), np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
+        elif kind == "accel_sm":
+            sp.add_accelerometer_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["g"], run["q_ib"], run["r_b"],
+                                          run["M"], run["size_effect"], np.array(run["t"]), np.array(run["meas"]),
+                                          np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
+        elif kind == "gyro_sm":
+            sp.add_gyroscope_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], run["q_gi"], run["M"],
+                                      run["Ma"], run["g"], run["r_b"], np.array(run["t"]), np.array(run["meas"]),
+                                      np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
         run_key, run = None, None
 
     def start(key, **fields):
@@ -792,15 +948,20 @@ def lower(problem):
             run["t"].append(m["time"]); run["dir"].append(m["dir"]); run["range"].append(m["range"]); run["sinv"].append(m["sinv"])
             run["q_pw"].append(h(m["q_pw"])); run["t_pw"].append(h(m["t_pw"]))
         elif isinstance(term, EuclideanError):
-            m = _match_accel(term)
-            kind = "accel"
+            m = None
+            for kind, matcher in (("accel", _match_accel), ("gyro", _match_gyro), ("accel_sm", _match_accel_sm),
+                                  ("gyro_sm", _match_gyro_sm)):
+                m = matcher(term)
+                if m is not None:
+                    break
             if m is None:
-                m, kind = _match_gyro(term), "gyro"
-            if m is None:
-                raise UnsupportedErrorTerm("euclidean error that is neither the accelerometer nor the gyroscope form")
-            key = (kind, id(m["spline"]), id(m["q_ib"]), id(m["bias_spline"]), id(m["bias_dv"]), id(m.get("g")), id(m.get("r_b")), mk)
+                raise UnsupportedErrorTerm("euclidean error that is neither an accelerometer nor a gyroscope form of the three IMU models")
+            se = m.get("size_effect")
+            key = (kind, id(m["spline"]), id(m["q_ib"]), id(m["bias_spline"]), id(m["bias_dv"]), id(m.get("g")), id(m.get("r_b")),
+                   id(m.get("M")), id(m.get("Ma")), id(m.get("q_gi")), tuple(id(o) for o in se) if se else None, mk)
             start(key, spline=h(m["spline"]), bias_spline=h(m["bias_spline"]), bias_dv=h(m["bias_dv"]), q_ib=h(m["q_ib"]),
-                  g=h(m.get("g")), r_b=h(m.get("r_b")), mest=term.mest, t=[], meas=[], sinv=[])
+                  g=h(m.get("g")), r_b=h(m.get("r_b")), M=h(m.get("M")), Ma=h(m.get("Ma")), q_gi=h(m.get("q_gi")),
+                  size_effect=[h(o) for o in se] if se else None, mest=term.mest, t=[], meas=[], sinv=[])
             run["t"].append(m["t"]); run["meas"].append(m["meas"]); run["sinv"].append(m["sinv"])
         else:
             raise UnsupportedErrorTerm("error term type %s is not lowered" % type(term).__name__)

@@ -11,7 +11,10 @@ from multical_amd import spec as S
 from multical_amd import synth
 
 
-def build_like_the_reference(W, state, meas):
+def build_like_the_reference(W, state, meas, imu_model="calibrated", extras=None):
+    """imu_model: "calibrated" (sens.Imu), "scale_misalignment" (sens.ScaledMisalignedImu) or "size_effect"
+    (sens.ScaledMisalignedSizeEffectImu); extras[k]: values of IMU k's additional design variables (the reference starts
+    them at identity / zero, sensors_and_targets.py:1431-1447, 1586-1606)."""
     cfg = W["cfg"]
     problem = F.OptimizationProblem()
     # --- calibrator.initDesignVariables
@@ -41,7 +44,25 @@ def build_like_the_reference(W, state, meas):
         problem.addDesignVariable(r_b, F.HELPER_GROUP_ID)
         q_i_b.setActive(not imu["reference"])
         r_b.setActive(not imu["reference"])
-        imus.append((gyroBiasDv, accelBiasDv, q_i_b, r_b))
+        sm = None
+        if imu_model != "calibrated":            # ScaledMisalignedImu.addDesignVariables
+            ex = extras[k]
+            lower = np.array([[1, 0, 0], [1, 1, 0], [1, 1, 1]], dtype=int)
+            sm = dict(q_gyro_i=F.RotationQuaternionDv(ex["q_gi"]), M_accel=F.MatrixBasicDv(ex["M_a"], lower),
+                      M_gyro=F.MatrixBasicDv(ex["M_g"], lower), M_accel_gyro=F.MatrixBasicDv(ex["M_ag"], np.ones((3, 3), dtype=int)))
+            for name in ("q_gyro_i", "M_accel", "M_gyro", "M_accel_gyro"):
+                problem.addDesignVariable(sm[name], F.HELPER_GROUP_ID)
+                sm[name].setActive(True)
+            if imu_model == "size_effect":       # ScaledMisalignedSizeEffectImu.addDesignVariables
+                sm["arms"] = [F.EuclideanPointDv(v) for v in ex["arms"]]
+                for j, dv in enumerate(sm["arms"]):
+                    problem.addDesignVariable(dv, F.HELPER_GROUP_ID)
+                    dv.setActive(j > 0)          # rx_i stays fixed
+                sm["sel"] = [F.MatrixBasicDv(np.diag(np.eye(3)[j]), np.zeros((3, 3), dtype=int)) for j in range(3)]
+                for dv in sm["sel"]:
+                    problem.addDesignVariable(dv, F.HELPER_GROUP_ID)
+                    dv.setActive(False)
+        imus.append((gyroBiasDv, accelBiasDv, q_i_b, r_b, sm))
     cams = []
     for k, cam in enumerate(W["cams"]):
         sc = state["cams"][k]
@@ -92,7 +113,7 @@ def build_like_the_reference(W, state, meas):
                 problem.addErrorTerm(rerr)
     # --- Imu.addAccelerometerErrorTerms / addGyroscopeErrorTerms / addBiasMotionTerms
     for k, imu in enumerate(W["imus"]):
-        gyroBiasDv, accelBiasDv, q_i_b, r_b_dv = imus[k]
+        gyroBiasDv, accelBiasDv, q_i_b, r_b_dv, sm = imus[k]
         mest_a = F.HuberMEstimator(cfg.huber_accel) if cfg.huber_accel > 0 else F.NoMEstimator()
         mest_g = F.HuberMEstimator(cfg.huber_gyro) if cfg.huber_gyro > 0 else F.NoMEstimator()
         for j, tk in enumerate(imu["t"]):
@@ -104,7 +125,21 @@ def build_like_the_reference(W, state, meas):
             w_dot_b = poseDv.angularAccelerationBodyFrame(tk)
             C_i_b = q_i_b.toExpression()
             r_b = r_b_dv.toExpression()
-            a = C_i_b * (C_b_w * (a_w - g_w) + w_dot_b.cross(r_b) + w_b.cross(w_b.cross(r_b)))
+            if imu_model == "calibrated":
+                a = C_i_b * (C_b_w * (a_w - g_w) + w_dot_b.cross(r_b) + w_b.cross(w_b.cross(r_b)))
+            elif imu_model == "scale_misalignment":
+                M = sm["M_accel"].toExpression()
+                a = M * (C_i_b * (C_b_w * (a_w - g_w) + w_dot_b.cross(r_b) + w_b.cross(w_b.cross(r_b))))
+            else:
+                M = sm["M_accel"].toExpression()
+                rx_b = r_b_dv.toExpression() + C_i_b.inverse() * sm["arms"][0].toExpression()
+                ry_b = r_b_dv.toExpression() + C_i_b.inverse() * sm["arms"][1].toExpression()
+                rz_b = r_b_dv.toExpression() + C_i_b.inverse() * sm["arms"][2].toExpression()
+                Ix, Iy, Iz = [dv.toExpression() for dv in sm["sel"]]
+                a = M * (C_i_b * (C_b_w * (a_w - g_w)) +
+                         Ix * (C_i_b * (w_dot_b.cross(rx_b) + w_b.cross(w_b.cross(rx_b)))) +
+                         Iy * (C_i_b * (w_dot_b.cross(ry_b) + w_b.cross(w_b.cross(ry_b)))) +
+                         Iz * (C_i_b * (w_dot_b.cross(rz_b) + w_b.cross(w_b.cross(rz_b)))))
             aerr = F.EuclideanError(meas["accel"][k][j], np.eye(3) * (1.0 / cfg.accel_sigma) ** 2, a + b_i)
             aerr.setMEstimatorPolicy(mest_a)
             problem.addErrorTerm(aerr)
@@ -112,7 +147,16 @@ def build_like_the_reference(W, state, meas):
             tk = float(tk)
             w_b = poseDv.angularVelocityBodyFrame(tk)
             b_i = gyroBiasDv.toEuclideanExpression(tk, 0)
-            w = q_i_b.toExpression() * w_b
+            if imu_model == "calibrated":
+                w = q_i_b.toExpression() * w_b
+            else:
+                w_dot_b = poseDv.angularAccelerationBodyFrame(tk)
+                C_b_w = poseDv.orientation(tk).inverse()
+                a_w = poseDv.linearAcceleration(tk)
+                r_b = r_b_dv.toExpression()
+                a_b = C_b_w * (a_w - g_w) + w_dot_b.cross(r_b) + w_b.cross(w_b.cross(r_b))
+                C_gyro_b = sm["q_gyro_i"].toExpression() * q_i_b.toExpression()
+                w = sm["M_gyro"].toExpression() * (C_gyro_b * w_b) + sm["M_accel_gyro"].toExpression() * (C_gyro_b * a_b)
             gerr = F.EuclideanError(meas["gyro"][k][j], np.eye(3) * (1.0 / cfg.gyro_sigma) ** 2, w + b_i)
             gerr.setMEstimatorPolicy(mest_g)
             problem.addErrorTerm(gerr)
@@ -236,3 +280,45 @@ def test_lowered_problem_on_the_gpu(lowered, small_oracle):
     assert np.abs(e1 - e0).max() <= 1e-9 * np.abs(e0).max()
     assert np.abs(Cx1 - Cx0).max() <= 1e-9 * np.abs(Cx0).max()
     assert np.abs(rhs1 - rhs0).max() <= 1e-9 * np.abs(rhs0).max()
+
+
+@pytest.mark.parametrize("model", ["scale_misalignment", "size_effect"])
+def test_imu_models_lower_to_the_same_problem(small_problem, model):
+    """The expression trees of ScaledMisalignedImu / ScaledMisalignedSizeEffectImu (sensors_and_targets.py:1449-1550,
+    1608-1661), built statement by statement, lower to accel_sm / gyro_sm batches that are the same problem as the one
+    written down directly (test_variants.make_variant).  The two descriptions add the extra design variables at different
+    places of the problem, so block indices differ; what must agree is everything that does not depend on the order:
+    dimensions, the cost, the residual vector, and the norms / traces of b and H."""
+    from oracle_api import OracleApi
+    from test_variants import make_variant
+    direct = make_variant(small_problem["spec"], model)
+    val = lambda h: direct.ops[h][1]["params"]
+    extras = []
+    for _, k, d in direct.batch_ops():
+        if k == "gyro_sm":
+            acc = next(dd for _, kk, dd in direct.batch_ops() if kk == "accel_sm" and dd["dv_q_ib"] == d["dv_q_ib"])
+            ex = dict(q_gi=val(d["dv_q_gi"]), M_g=val(d["dv_M"]), M_ag=val(d["dv_Ma"]), M_a=val(acc["dv_M"]))
+            if acc["size_effect"]:
+                ex["arms"] = [val(h) for h in acc["size_effect"][:3]]
+            extras.append(ex)
+    W, meas = small_problem["W"], small_problem["meas"]
+    problem = build_like_the_reference(W, synth.initial_state(W), meas, imu_model=model, extras=extras)
+    spec, _ = F.lower(problem)
+    assert [k for _, k, _ in spec.batch_ops()] == [k for _, k, _ in direct.batch_ops()]
+    o0, o1 = OracleApi(), OracleApi()
+    direct.emit(o0)
+    o0.finalize()
+    spec.emit(o1)
+    o1.finalize()
+    assert (o0.j_rows, o0.j_cols, o0.n_blocks, o0.n_terms) == (o1.j_rows, o1.j_cols, o1.n_blocks, o1.n_terms)
+    J0, e0 = o0.evaluate_error(True)
+    J1, e1 = o1.evaluate_error(True)
+    assert abs(J1 - J0) <= 1e-12 * abs(J0)
+    assert np.abs(e1 - e0).max() <= 1e-12 * np.abs(e0).max()
+    Cp0, Ci0, Cx0, rhs0 = o0.build_system(True)
+    Cp1, Ci1, Cx1, rhs1 = o1.build_system(True)
+    assert Cx0.size == Cx1.size
+    assert abs(np.linalg.norm(rhs1) - np.linalg.norm(rhs0)) <= 1e-10 * np.linalg.norm(rhs0)
+    d0, d1 = Cx0[Cp0[1:] - 1], Cx1[Cp1[1:] - 1]
+    assert abs(d1.sum() - d0.sum()) <= 1e-10 * d0.sum()
+    assert abs(np.linalg.norm(Cx1) - np.linalg.norm(Cx0)) <= 1e-10 * np.linalg.norm(Cx0)

@@ -270,3 +270,28 @@ def test_jacobian_transpose_backend_on_the_spline_problem(small_problem, model):
         vg = g.build_jacobian_transpose(use_mest)
         assert np.abs(vg - v).max() <= RTOL * np.abs(v).max()
         assert np.array_equal(vg == 0.0, v == 0.0)           # structural zeros of the padded coefficients
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["scale_misalignment", "size_effect"])
+def test_levenberg_marquardt_with_imu_models_matches_oracle(small_problem, model):
+    """End to end with the other IMU models: mc_optimize (C++ Optimizer2 + LM + host Cholesky over the HIP backend)
+    against the oracle's run of the same loop -- same step sequence, final design variables (MatrixBasic ones included)
+    within 1e-7."""
+    from multical_amd.backend import HipApi
+    from oracle_api import OracleApi
+    sp = make_variant(small_problem["spec"], model)
+    g, o = HipApi(0), OracleApi()
+    ids, oids = sp.emit(g), sp.emit(o)
+    o.finalize()
+    iters = 5
+    r = g.optimize(maxIterations=iters, convergenceDeltaX=1e-5, convergenceJDescentRatioThreshold=1e-6, levenbergMarquardtLambdaInit=10.0)
+    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 4)
+    assert (r["iterations"], r["failedIterations"]) == (ro["iterations"], ro["failedIterations"])
+    assert abs(r["JFinal"] - ro["JFinal"]) <= 1e-7 * ro["JFinal"]
+    worst, n_matrix = 0.0, 0
+    for h, v in ids.items():
+        if isinstance(v, int) and sp.ops[h][0] == "dv":
+            worst = max(worst, np.abs(g.dv_params(v) - o.dv_params(oids[h])).max())
+            n_matrix += sp.ops[h][1]["kind"] == S.DV_MATRIX_BASIC
+    assert n_matrix >= 6 and worst <= 1e-7, (n_matrix, worst)
