@@ -183,6 +183,17 @@ int mc_revert_update(mc_context* ctx);
 /* current parameters of a design variable (DesignVariable::getParameters); returns the count.
  * EUCLIDEAN_DIRECTION reports its 3x3 rotation (row major) followed by the magnitude. */
 int mc_get_dv_params(mc_context* ctx, int dv, double* out);
+/* LiDAR.findPointsOnTarget (kalibr_sensor_calibration/sensors_and_targets.py:199-235), the data-association step the
+ * front-end re-runs before every LiDAR optimisation (calibrator.py:70-89): transformMeasurementsToWorldFrame + _onPlane,
+ * a per-reading Python loop there.  Evaluated at the CURRENT state held by the context (after mc_finalize / mc_optimize).
+ * points[n,4] = x y z t in the sensor frame; plane_min / plane_max [n_planes,3] = the targets' grid ranges
+ * (CalibrationTarget.range, :111-114); threshold = slack along the plane normal.  mask_out[n]: bit p set when reading i
+ * lies inside target p's box, bit 31 set when its time lies strictly inside the spline (the readings the reference
+ * keeps; others get no target bits).  world_out (optional, [n,3]): the readings in the world frame (LiDAR.pointCloud). */
+int mc_lidar_find_points_on_targets(mc_context* ctx, int pose_spline, int dv_time_offset, int dv_q_l_b, int dv_t_l_b,
+                                    int n_planes, const int* dv_q_p_w, const int* dv_t_p_w, const double* plane_min,
+                                    const double* plane_max, double threshold, int n, const double* points,
+                                    unsigned* mask_out, double* world_out);
 /* asynchronous device errors raised by the last kernels (e.g. "Spline Coefficient Buffer Exceeded",
  * BSplineExpressions.cpp:447): 0 = none. */
 int mc_device_status(mc_context* ctx);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "mc_revert_update": (C.c_int, [_ctx]),
     "mc_get_dv_params": (C.c_int, [_ctx, C.c_int, _dp]),
     "mc_device_status": (C.c_int, [_ctx]),
+    "mc_lidar_find_points_on_targets": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _dp, C.c_double,
+                                                  C.c_int, _dp, C.POINTER(C.c_uint), _dp]),
     "mc_jt_nnz": (C.c_int, [_ctx, C.POINTER(C.c_longlong)]),
     "mc_get_jt_pattern": (C.c_int, [_ctx, _ip, _ip]),
     "mc_build_jacobian_transpose": (C.c_int, [_ctx, C.c_int, _dp]),

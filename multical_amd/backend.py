@@ -223,6 +223,24 @@ class HipApi(object):
         n = self._chk(self.lib.mc_get_dv_params(self.ctx, dv, _dp(out)))
         return out[:n].copy()
 
+    def lidar_find_points_on_targets(self, pose_spline, dv_toff, dv_q_lb, dv_t_lb, dv_q_pw, dv_t_pw, plane_min, plane_max, threshold,
+                                     points, want_world=False):
+        """LiDAR.findPointsOnTarget at the current state.  Returns (kept, inliers, world): `kept` = indices of the readings
+        whose time lies inside the spline (the reference's filtered lidarData), `inliers[p]` = indices INTO `kept` of the
+        readings on target p (what TargetObservation.inliers holds), world = kept readings in the world frame or None."""
+        pts = _f64(points).reshape(-1, 4)
+        q, t = _i32(dv_q_pw), _i32(dv_t_pw)
+        lo, hi = _f64(plane_min).reshape(-1, 3), _f64(plane_max).reshape(-1, 3)
+        mask = np.zeros(pts.shape[0], np.uint32)
+        world = np.zeros((pts.shape[0], 3)) if want_world else None
+        self._chk(self.lib.mc_lidar_find_points_on_targets(self.ctx, pose_spline, dv_toff, dv_q_lb, dv_t_lb, q.size, _ip(q), _ip(t),
+                                                           _dp(lo), _dp(hi), float(threshold), pts.shape[0], _dp(pts),
+                                                           mask.ctypes.data_as(C.POINTER(C.c_uint)), _dp(world)))
+        kept = np.nonzero(mask >> 31)[0]
+        km = mask[kept]
+        inliers = [np.nonzero((km >> p) & 1)[0] for p in range(q.size)]
+        return kept, inliers, (world[kept] if want_world else None)
+
     def check_status(self):
         s = self._chk(self.lib.mc_device_status(self.ctx))
         if s:

@@ -920,6 +920,48 @@ __global__ __launch_bounds__(256) void k_unpack(const int* __restrict__ idx, int
   if (i < n) dst[idx[i]] = src[i];
 }
 
+// LiDAR.findPointsOnTarget (kalibr_sensor_calibration/sensors_and_targets.py:199-235): the front-end's per-point Python
+// loop -- transformMeasurementsToWorldFrame (:199-219: p_w = T_w_b(t + d) * inverse(T_l_b) * p for every reading whose
+// time lies strictly inside the spline) followed by _onPlane (:221-227: p_w into every target's frame, strict box test
+// with `threshold` of slack along the plane normal).  One lane per reading; bit p of the mask = inside target p's box,
+// bit 31 = time inside the spline (the readings the reference keeps).
+struct AssocPlanes { int n; int q_off[30], t_off[30]; double lo[30][3], hi[30][3]; };
+__global__ __launch_bounds__(256) void k_lidar_associate(SplineView sp, const double* __restrict__ x, int toff_off, int q_lb_off,
+                                                         int t_lb_off, AssocPlanes pl, const double* __restrict__ pts, int n,
+                                                         unsigned* __restrict__ mask, double* __restrict__ world) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double t = pts[4 * (size_t)i + 3] + (toff_off >= 0 ? x[toff_off] : 0.0);
+  unsigned m = 0;
+  double pw[3] = {0.0, 0.0, 0.0};
+  if (t > sp.t_min && t < sp.t_max) {
+    PoseSample ps;
+    if (pose_sample<1>(sp, x, t, ps)) {
+      m = 0x80000000u;
+      Rigid Tlb;
+      load_rigid(x, q_lb_off, t_lb_off, Tlb);
+      const double p[3] = {pts[4 * (size_t)i], pts[4 * (size_t)i + 1], pts[4 * (size_t)i + 2]};
+      const double d[3] = {p[0] - Tlb.r[0], p[1] - Tlb.r[1], p[2] - Tlb.r[2]};
+      double pb[3];
+      m3_tmulv(Tlb.C, d, pb);             // inverse(T_l_b) * p
+      m3_mulv(ps.C, pb, pw);
+      pw[0] += ps.c[0]; pw[1] += ps.c[1]; pw[2] += ps.c[2];
+      for (int k = 0; k < pl.n; ++k) {
+        Rigid Tpw;
+        load_rigid(x, pl.q_off[k], pl.t_off[k], Tpw);
+        double q[3];
+        m3_mulv(Tpw.C, pw, q);
+        bool in = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const double v = q[a] + Tpw.r[a]; in = in && v > pl.lo[k][a] && v < pl.hi[k][a]; }
+        if (in) m |= 1u << k;
+      }
+    }
+  }
+  mask[i] = m;
+  if (world) { world[3 * (size_t)i] = pw[0]; world[3 * (size_t)i + 1] = pw[1]; world[3 * (size_t)i + 2] = pw[2]; }
+}
+
 // Optimizer2::applyStateUpdate (Optimizer2.cpp:292-309) + every DesignVariable::updateImplementation
 struct UpdRec { int kind, dim, off, col; double scaling; int mask; };
 __global__ __launch_bounds__(256) void k_update(const UpdRec* __restrict__ recs, int n, const double* __restrict__ dx, double* x) {
@@ -1710,6 +1752,46 @@ int mc_get_dv_params(mc_context* ctx, int dv, double* out) {
     HIP_CHECK(hipMemcpy(out, ctx->x.p + d.off, sizeof(double) * d.nparam, hipMemcpyDeviceToHost));
   } else std::memcpy(out, &ctx->P.x[d.off], sizeof(double) * d.nparam);
   return d.nparam;
+  MC_CATCH(ctx, -1)
+}
+int mc_lidar_find_points_on_targets(mc_context* ctx, int pose_spline, int dv_time_offset, int dv_q_l_b, int dv_t_l_b, int n_planes,
+                                    const int* dv_q_p_w, const int* dv_t_p_w, const double* plane_min, const double* plane_max,
+                                    double threshold, int n, const double* points, unsigned* mask_out, double* world_out) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  Problem& P = ctx->P;
+  P.checkSpline(pose_spline, 6);
+  P.checkDv(dv_q_l_b, DV_ROTATION_QUATERNION); P.checkDv(dv_t_l_b, DV_EUCLIDEAN_POINT);
+  if (dv_time_offset >= 0) P.checkDv(dv_time_offset, DV_SCALAR);
+  if (n_planes < 0 || n_planes > 30) throw std::invalid_argument("at most 30 targets");
+  if (n < 0 || !mask_out || (n > 0 && !points)) throw std::invalid_argument("bad point / mask arguments");
+  AssocPlanes pl;
+  std::memset(&pl, 0, sizeof pl);
+  pl.n = n_planes;
+  for (int k = 0; k < n_planes; ++k) {
+    P.checkDv(dv_q_p_w[k], DV_ROTATION_QUATERNION); P.checkDv(dv_t_p_w[k], DV_EUCLIDEAN_POINT);
+    pl.q_off[k] = P.dvs[dv_q_p_w[k]].off; pl.t_off[k] = P.dvs[dv_t_p_w[k]].off;
+    for (int a = 0; a < 3; ++a) {
+      pl.lo[k][a] = plane_min[3 * k + a] - (a == 2 ? threshold : 0.0);
+      pl.hi[k][a] = plane_max[3 * k + a] + (a == 2 ? threshold : 0.0);
+    }
+  }
+  if (n == 0) return 0;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  DevBuf<double> dpts, dworld;
+  DevBuf<unsigned> dmask;
+  {
+    std::vector<double> hp(points, points + 4 * (size_t)n);
+    dpts.upload(hp);
+  }
+  dmask.alloc(n);
+  if (world_out) dworld.alloc(3 * (size_t)n);
+  hipLaunchKernelGGL(k_lidar_associate, dim3((n + 255) / 256), dim3(256), 0, 0, P.splineView(pose_spline, ctx->knots.p, ctx->basis.p),
+                     ctx->x.p, dv_time_offset >= 0 ? P.dvs[dv_time_offset].off : -1, P.dvs[dv_q_l_b].off, P.dvs[dv_t_l_b].off, pl,
+                     dpts.p, n, dmask.p, world_out ? dworld.p : nullptr);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpy(mask_out, dmask.p, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+  if (world_out) HIP_CHECK(hipMemcpy(world_out, dworld.p, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
   MC_CATCH(ctx, -1)
 }
 int mc_device_status(mc_context* ctx) {

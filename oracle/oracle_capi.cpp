@@ -357,6 +357,44 @@ int orc_add_lidar_batch(void* h, int spline, int dvToff, int dvQlb, int dvTlb, i
   ORC_CATCH(P, -1)
 }
 
+// LiDAR.findPointsOnTarget, sensors_and_targets.py:199-235: transformMeasurementsToWorldFrame (per reading,
+// T_w_b(t + offset) from the spline, general inverse of T_l_b) then _onPlane per target.  mask bit p: on target p;
+// bit 31: time strictly inside the spline.  margin[i] (optional): smallest distance of any tested coordinate to a box face.
+int orc_lidar_find_points_on_targets(void* h, int spline, int dvToff, int dvQlb, int dvTlb, int nPlanes, const int* dvQpw,
+                                     const int* dvTpw, const double* planeMin, const double* planeMax, double threshold, int n,
+                                     const double* pts, unsigned* mask, double* world, double* margin) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  const BSplinePose& sp = P->splines[spline]->spline;
+  const double off = dvToff >= 0 ? P->dvAs<ScalarDv>(dvToff)->s : 0.0;
+  Mat T_b_l = inverse(P->basicT(dvQlb, dvTlb)->toT());
+  std::vector<Mat> T_p_w;
+  for (int k = 0; k < nPlanes; ++k) T_p_w.push_back(P->basicT(dvQpw[k], dvTpw[k])->toT());
+  for (int i = 0; i < n; ++i) {
+    mask[i] = 0;
+    if (margin) margin[i] = 1e300;
+    double tk = pts[4 * i + 3] + off;
+    if (!(tk > sp.t_min() && tk < sp.t_max())) { if (world) world[3 * i] = world[3 * i + 1] = world[3 * i + 2] = 0.0; continue; }
+    mask[i] = 0x80000000u;
+    Mat p(4, 1);
+    p[0] = pts[4 * i]; p[1] = pts[4 * i + 1]; p[2] = pts[4 * i + 2]; p[3] = 1.0;
+    Mat pw = sp.transformation(tk) * (T_b_l * p);
+    if (world) { world[3 * i] = pw[0]; world[3 * i + 1] = pw[1]; world[3 * i + 2] = pw[2]; }
+    for (int k = 0; k < nPlanes; ++k) {
+      Mat q = T_p_w[k] * pw;
+      bool in = true;
+      for (int a = 0; a < 3; ++a) {
+        double lo = planeMin[3 * k + a] - (a == 2 ? threshold : 0.0), hi = planeMax[3 * k + a] + (a == 2 ? threshold : 0.0);
+        in = in && q[a] > lo && q[a] < hi;
+        if (margin) margin[i] = std::fmin(margin[i], std::fmin(std::fabs(q[a] - lo), std::fabs(q[a] - hi)));
+      }
+      if (in) mask[i] |= 1u << k;
+    }
+  }
+  return 0;
+  ORC_CATCH(P, -1)
+}
+
 // F7: asp.BSplineEuclideanMotionError / addMotionErrorTerms
 int orc_add_motion_term(void* h, int spline, const double* W, int order) {
   Problem* P = (Problem*)h;

@@ -223,6 +223,17 @@ class OracleApi(object):
         rc = self._chk(self.lib.orc_solve_system(self.h, C.c_double(lam), _d(dx)))
         return rc == 0, dx
 
+    def lidar_find_points_on_targets(self, spline, dv_toff, dv_q_lb, dv_t_lb, dv_q_pw, dv_t_pw, plane_min, plane_max, threshold, points):
+        pts = _f64(points).reshape(-1, 4)
+        q, t = _i32(dv_q_pw), _i32(dv_t_pw)
+        lo, hi = _f64(plane_min).reshape(-1, 3), _f64(plane_max).reshape(-1, 3)
+        mask, world, margin = np.zeros(pts.shape[0], np.uint32), np.zeros((pts.shape[0], 3)), np.zeros(pts.shape[0])
+        self._chk(self.lib.orc_lidar_find_points_on_targets(self.h, C.c_int(spline), C.c_int(dv_toff), C.c_int(dv_q_lb), C.c_int(dv_t_lb),
+                                                            C.c_int(q.size), _i(q), _i(t), _d(lo), _d(hi), C.c_double(threshold),
+                                                            C.c_int(pts.shape[0]), _d(pts), mask.ctypes.data_as(C.POINTER(C.c_uint)),
+                                                            _d(world), _d(margin)))
+        return mask, world, margin
+
     def optimize(self, max_iterations=30, lambda_init=10.0, convergence_delta_x=1e-5, convergence_j_ratio=1e-6, n_threads=1):
         out = np.zeros(7)
         self._chk(self.lib.orc_optimize(self.h, C.c_int(max_iterations), C.c_double(lambda_init), C.c_double(convergence_delta_x),
