@@ -239,6 +239,11 @@ const char* mc_cholesky_last_error(const mc_cholesky* h);
 int mc_cholesky_analyze(mc_cholesky* h, int n, const int* Cp, const int* Ci, int n_blocks, const int* block_base);
 int mc_cholesky_factorize(mc_cholesky* h, const double* Cx);
 int mc_cholesky_solve(mc_cholesky* h, const double* b, double* x);
+/* LinearSolverCholmod::solvePattern (linear_solver_cholmod.h:114-165), what BlockCholeskyLinearSystemSolver::
+ * computeCovarianceBlocks (BlockCholeskyLinearSystemSolver.cpp:122-148) calls for --recover-covariance: blocks
+ * (block_row[k], block_col[k]) of the inverse of the last factorised matrix, block k row major at out + offsets[k]. */
+int mc_cholesky_covariance_blocks(mc_cholesky* h, int n_pairs, const int* block_row, const int* block_col,
+                                  const long long* offsets, double* out);
 int mc_cholesky_stats(const mc_cholesky* h, int* n_dense_blocks, long long* nnz_factor, double* flops);
 int mc_cholesky_block_permutation(const mc_cholesky* h, int* perm /* n_blocks */);
 

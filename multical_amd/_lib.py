@@ -97,6 +97,7 @@ SIGNATURES.update({
     "mc_cholesky_analyze": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _ip]),
     "mc_cholesky_factorize": (C.c_int, [C.c_void_p, _dp]),
     "mc_cholesky_solve": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mc_cholesky_covariance_blocks": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(C.c_longlong), _dp]),
     "mc_cholesky_stats": (C.c_int, [C.c_void_p, _ip, C.POINTER(C.c_longlong), _dp]),
     "mc_cholesky_block_permutation": (C.c_int, [C.c_void_p, _ip]),
     "mc_optimizer_options_default": (None, [C.POINTER(OptimizerOptions)]),

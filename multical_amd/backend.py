@@ -342,6 +342,18 @@ class HostSparseCholesky(object):
         self.lib.mc_cholesky_stats(self.h, C.byref(nd), C.byref(nnz), C.byref(fl))
         return dict(dense_blocks=nd.value, factor_nnz=nnz.value, factor_flops=fl.value)
 
+    def covariance_blocks(self, pairs, block_base):
+        """blocks (i, j) of the inverse of the last factorised matrix (LinearSolverCholmod::solvePattern)"""
+        bb = _i32(block_base)
+        bi, bj = _i32([p[0] for p in pairs]), _i32([p[1] for p in pairs])
+        sizes = (bb[bi + 1] - bb[bi]).astype(np.int64) * (bb[bj + 1] - bb[bj])
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        out = np.zeros(int(off[-1]))
+        rc = self.lib.mc_cholesky_covariance_blocks(self.h, bi.size, _ip(bi), _ip(bj), off.ctypes.data_as(C.POINTER(C.c_longlong)), _dp(out))
+        if rc != 0:
+            raise BackendError(self.lib.mc_cholesky_last_error(self.h).decode())
+        return [out[off[k]:off[k + 1]].reshape(bb[bi[k] + 1] - bb[bi[k]], bb[bj[k] + 1] - bb[bj[k]]) for k in range(bi.size)]
+
     def solve(self, n, Cp, Ci, Cx, b, block_base=None):
         if self._pattern is None or self._pattern[0] != n or self._pattern[3] != len(Ci):
             self.analyze(n, Cp, Ci, block_base)
@@ -417,6 +429,17 @@ class HipBlockCholeskyLinearSystemSolver(object):
         if x is None:
             return False, np.zeros(self.api.j_cols)
         return True, x
+
+    def computeCovarianceBlocks(self, blockIndices):
+        """BlockCholeskyLinearSystemSolver::computeCovarianceBlocks (:122-148)"""
+        if self._useDiagonalConditioner:
+            self._Cx[self._diag_pos] += self._diag * self._diag
+        rc = self._host.lib.mc_cholesky_factorize(self._host.h, _dp(self._Cx))
+        if self._useDiagonalConditioner:
+            self._Cx[self._diag_pos] -= self._diag
+        if rc != 0:
+            raise BackendError("Unable to retrieve covariance")
+        return self._host.covariance_blocks(blockIndices, self.api.block_bases())
 
     def rhs(self):
         return self._rhs

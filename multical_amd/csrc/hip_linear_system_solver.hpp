@@ -138,6 +138,30 @@ class HipBlockCholeskyLinearSystemSolver : public LinearSystemSolver {
       }
     return s;
   }
+  // BlockCholeskyLinearSystemSolver::computeCovarianceBlocks (:122-148): blocks of (H + conditioner^2)^-1 for the given
+  // (block row, block column) pairs, with the same augment / un-augment sequence around the factorisation as solveSystem.
+  // Block k comes back row major in outP[k].  Throws like the reference's SM_ASSERT_TRUE when H is not positive definite.
+  void computeCovarianceBlocks(const std::vector<std::pair<int, int> >& blockIndices, std::vector<std::vector<double> >& outP) {
+    if (useDiagonalConditioner_)
+      for (int c = 0; c < jCols_; ++c) H_[Cp_[c + 1] - 1] += diagonalConditioner_[c] * diagonalConditioner_[c];
+    const bool ok = chol_.factorize(H_.data());
+    if (useDiagonalConditioner_)
+      for (int c = 0; c < jCols_; ++c) H_[Cp_[c + 1] - 1] -= diagonalConditioner_[c];
+    if (!ok) throw Exception("Unable to retrieve covariance");
+    std::vector<int> bi, bj;
+    std::vector<long long> off;
+    long long total = 0;
+    for (const auto& p : blockIndices) {
+      if (p.first < 0 || p.first >= nBlocks_ || p.second < 0 || p.second >= nBlocks_) throw Exception("block index out of range");
+      bi.push_back(p.first); bj.push_back(p.second); off.push_back(total);
+      total += (long long)(blockBase_[p.first + 1] - blockBase_[p.first]) * (blockBase_[p.second + 1] - blockBase_[p.second]);
+    }
+    std::vector<double> flat((std::size_t)total);
+    chol_.covarianceBlocks((int)bi.size(), bi.data(), bj.data(), off.data(), flat.data());
+    outP.resize(bi.size());
+    for (std::size_t k = 0; k < bi.size(); ++k)
+      outP[k].assign(flat.begin() + off[k], k + 1 < bi.size() ? flat.begin() + off[k + 1] : flat.end());
+  }
   // scalar CCS of the upper triangle, bit-exact fillCCS(upper) ordering
   const std::vector<int>& Cp() const { return Cp_; }
   const std::vector<int>& Ci() const { return Ci_; }
@@ -153,13 +177,13 @@ class HipBlockCholeskyLinearSystemSolver : public LinearSystemSolver {
     Ci_.assign(nnz_, 0);
     H_.assign(nnz_, 0.0);
     check(mc_get_pattern(ctx_, Cp_.data(), Ci_.data()));
-    std::vector<int> base(nBlocks_ + 1, 0);
-    check(mc_get_block_bases(ctx_, base.data()));
-    chol_.analyze(jCols_, Cp_.data(), Ci_.data(), nBlocks_, base.data());
+    blockBase_.assign(nBlocks_ + 1, 0);
+    check(mc_get_block_bases(ctx_, blockBase_.data()));
+    chol_.analyze(jCols_, Cp_.data(), Ci_.data(), nBlocks_, blockBase_.data());
   }
 
  private:
-  std::vector<int> Cp_, Ci_;
+  std::vector<int> Cp_, Ci_, blockBase_;
   std::vector<double> H_;
   BlockSparseCholesky chol_;
 };

@@ -221,6 +221,33 @@ class BlockSparseCholesky {
     }
   }
 
+  // Blocks (bi[k], bj[k]) of A^-1 (LinearSolverCholmod::solvePattern -> MarginalCovarianceCholesky in the reference,
+  // linear_solver_cholmod.h:114-165): block k is written row major (dim(bi) x dim(bj)) at out + offsets[k].  One pair of
+  // triangular solves per distinct scalar column asked for -- meant for the handful of calibration parameters
+  // Calibrator.recoverCovariance reads (calibrator.py:236-249), not for the whole matrix.
+  void covarianceBlocks(int n_pairs, const int* bi, const int* bj, const long long* offsets, double* out) const {
+    if (!factored_) throw std::logic_error("covarianceBlocks before a successful factorize");
+    std::vector<std::vector<int>> byCol(nb_);
+    for (int k = 0; k < n_pairs; ++k) {
+      if (bi[k] < 0 || bi[k] >= nb_ || bj[k] < 0 || bj[k] >= nb_) throw std::invalid_argument("block index out of range");
+      byCol[bj[k]].push_back(k);
+    }
+    std::vector<double> rhs(n_), x(n_);
+    for (int J = 0; J < nb_; ++J) {
+      if (byCol[J].empty()) continue;
+      const int dJ = obase_[J + 1] - obase_[J];
+      for (int c = 0; c < dJ; ++c) {
+        std::fill(rhs.begin(), rhs.end(), 0.0);
+        rhs[obase_[J] + c] = 1.0;
+        solve(rhs.data(), x.data());
+        for (int k : byCol[J]) {
+          const int I = bi[k], dI = obase_[I + 1] - obase_[I];
+          for (int r = 0; r < dI; ++r) out[offsets[k] + (long long)r * dJ + c] = x[obase_[I] + r];
+        }
+      }
+    }
+  }
+
   const Stats& stats() const { return stats_; }
   const std::vector<int>& blockPermutation() const { return perm_; }   // position -> original block
   bool analyzed() const { return analyzed_; }

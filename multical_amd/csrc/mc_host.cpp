@@ -97,6 +97,11 @@ int mc_cholesky_solve(mc_cholesky* h, const double* b, double* x) {
   try { h->chol.solve(b, x); return 0; }
   catch (const std::exception& e) { h->err = e.what(); return -1; }
 }
+int mc_cholesky_covariance_blocks(mc_cholesky* h, int n_pairs, const int* block_row, const int* block_col, const long long* offsets,
+                                  double* out) {
+  try { h->chol.covarianceBlocks(n_pairs, block_row, block_col, offsets, out); return 0; }
+  catch (const std::exception& e) { h->err = e.what(); return -1; }
+}
 int mc_cholesky_stats(const mc_cholesky* h, int* n_dense_blocks, long long* nnz_factor, double* flops) {
   const BlockSparseCholesky::Stats& s = h->chol.stats();
   if (n_dense_blocks) *n_dense_blocks = s.n_dense_blocks;

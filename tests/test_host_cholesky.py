@@ -157,3 +157,25 @@ def test_rejects_a_lower_triangular_pattern():
     Cp, Ci = L.indptr.astype(np.int32), L.indices.astype(np.int32)
     rc = c.lib.mc_cholesky_analyze(c.h, 4, _ip(Cp), _ip(Ci), 0, None)
     assert rc == -1 and b"upper" in c.lib.mc_cholesky_last_error(c.h)
+
+
+def test_covariance_blocks_match_the_dense_inverse():
+    """LinearSolverCholmod::solvePattern: selected blocks of H^-1 (diagonal and off-diagonal, band and border)."""
+    rng = np.random.default_rng(21)
+    U, base, H = arrowhead_problem(rng, n_band=80)
+    c = Chol()
+    c.analyze(U, base)
+    assert c.factorize(U.data) == 0
+    nb = len(base) - 1
+    pairs = [(nb - 1, nb - 1), (nb - 2, nb - 1), (3, 3), (3, nb - 1), (10, 4), (nb - 3, 7)]
+    bi, bj = np.array([p[0] for p in pairs], np.int32), np.array([p[1] for p in pairs], np.int32)
+    sizes = (base[bi + 1] - base[bi]).astype(np.int64) * (base[bj + 1] - base[bj])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    out = np.zeros(int(off[-1]))
+    rc = c.lib.mc_cholesky_covariance_blocks(c.h, len(pairs), _ip(bi), _ip(bj), off.ctypes.data_as(C.POINTER(C.c_longlong)), _dp(out))
+    assert rc == 0, c.lib.mc_cholesky_last_error(c.h)
+    Pinv = np.linalg.inv(H)
+    for k, (i, j) in enumerate(pairs):
+        blk = out[off[k]:off[k + 1]].reshape(base[i + 1] - base[i], base[j + 1] - base[j])
+        want = Pinv[base[i]:base[i + 1], base[j]:base[j + 1]]
+        assert np.abs(blk - want).max() <= 1e-9 * np.abs(Pinv).max()
