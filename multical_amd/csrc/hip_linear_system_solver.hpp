@@ -39,8 +39,9 @@ class LinearSystemSolver {
 
   // LinearSystemSolver::initMatrixStructure (LinearSystemSolver.cpp:117-138)
   void initMatrixStructure(bool useDiagonalConditioner) {
-    check(mc_finalize(ctx_));
     int nb = 0, nt = 0, nnz = 0;
+    // Optimizer2::initialize runs at the start of every optimize(); the structure of a context is frozen by the first one
+    if (mc_dims(ctx_, &jRows_, &jCols_, &nb, &nt, &nnz) < 0) check(mc_finalize(ctx_));
     check(mc_dims(ctx_, &jRows_, &jCols_, &nb, &nt, &nnz));
     nBlocks_ = nb; nnz_ = nnz;
     e_.assign(jRows_, 0.0);
