@@ -1061,6 +1061,30 @@ struct mc_context {
   LaunchUnit lu[N_LAUNCH];
   int n_jpart = 0;
   bool have_prev = false;
+  // The term families only meet in the fp64 atomics on Cx / rhs, so their launches are independent: each family goes to
+  // its own HIP stream (forked from / joined into the caller's stream with events) and the dispatcher fills the CUs one
+  // latency-bound kernel leaves idle with another's workgroups.  MC_SERIAL_LAUNCH=1 keeps everything on the caller's stream.
+  enum { N_SIDE = 3 };
+  hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr, nullptr, nullptr};
+  int side_state = 0;   // 0: not created yet, 1: ready, -1: disabled
+  ~mc_context() {
+    for (int i = 0; i < N_SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+  }
+  bool sideStreams() {
+    if (side_state == 0) {
+      const char* s = getenv("MC_SERIAL_LAUNCH");
+      if (s && s[0] == '1') { side_state = -1; return false; }
+      for (int i = 0; i < N_SIDE; ++i) {
+        HIP_CHECK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+      }
+      HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      side_state = 1;
+    }
+    return side_state == 1;
+  }
 
   void uploadStructure();
   void launchAll(int build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
@@ -1345,10 +1369,22 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     HIP_CHECK(hipMemsetAsync(dRhs, 0, sizeof(double) * P.j_cols, st));
   }
   if (dE && P.world > 1) HIP_CHECK(hipMemsetAsync(dE, 0, sizeof(double) * P.j_rows, st));
+  // per-launch timing (ev) needs the launches back to back on one stream
+  static const int side_of[N_LAUNCH] = {-1, -1, 0, 1, 2, 0};   // reprojection kernels stay on the caller's stream
+  const hipStream_t caller = st;
+  bool used[N_SIDE] = {false, false, false};
+  const bool fork = !ev && sideStreams();
+  if (fork) HIP_CHECK(hipEventRecord(ev_fork, caller));
   for (int l = 0; l < N_LAUNCH; ++l) {
     LaunchUnit& L = lu[l];
-    if (ev) HIP_CHECK(hipEventRecord((*ev)[l], st));
+    if (ev) HIP_CHECK(hipEventRecord((*ev)[l], caller));
     if (L.n_items == 0) continue;
+    st = caller;
+    if (fork && side_of[l] >= 0) {
+      const int s = side_of[l];
+      st = side[s];
+      if (!used[s]) { HIP_CHECK(hipStreamWaitEvent(st, ev_fork, 0)); used[s] = true; }
+    }
     switch (l) {
       case LAUNCH_REPROJ:
         hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p);
@@ -1378,6 +1414,9 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     }
     HIP_CHECK(hipGetLastError());
   }
+  st = caller;
+  for (int s = 0; s < N_SIDE; ++s)
+    if (used[s]) { HIP_CHECK(hipEventRecord(ev_join[s], side[s])); HIP_CHECK(hipStreamWaitEvent(st, ev_join[s], 0)); }
   if (ev) HIP_CHECK(hipEventRecord((*ev)[N_LAUNCH], st));
   if (!build || dJ) {
     double* out = dJ ? dJ : J.p;
