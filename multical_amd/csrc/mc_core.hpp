@@ -581,7 +581,7 @@ inline void Problem::finalize() {
         if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
           throw std::invalid_argument("a design variable plays two roles in one error term");
         int fp = internFootprint(pattern, written);
-        pushGroup(b.obs_first[o], b.obs_first[o + 1] - b.obs_first[o], fp, o, (double)o, 24);
+        pushGroup(b.obs_first[o], b.obs_first[o + 1] - b.obs_first[o], fp, o, (double)o, 1 << 30);
       }
     }
   }

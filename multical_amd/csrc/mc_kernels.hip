@@ -369,18 +369,6 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
   MC_MARK(6);   // image flush
 }
 
-// ---------------------------------------------------------------------------------------------
-// Generic group kernel: lanes 0..count-1 evaluate one term each into an LDS row tile (D rows per term,
-// C+1 columns, the last one the weighted residual); the wave then forms the group's J^T J / J^T e.
-template <class View> struct TermTraits;
-template <> struct TermTraits<StaticReprojBatchView> {
-  enum { D = 2 };
-  static __device__ __forceinline__ bool eval(const StaticReprojBatchView& b, const double* x, int k, bool useM, bool wantJ,
-                                              const FpView& f, double* J, int ld, double* e, TermOut& out, int*) {
-    return f2_term(b, x, k, useM, wantJ, f.rolecol, J, ld, e, out);
-  }
-};
-
 __device__ __forceinline__ int b_pose_first_block(const LidarBatchView& b) { return b.sp.first_block; }
 __device__ __forceinline__ int b_pose_first_col(const LidarBatchView& b) { return b.sp.first_col; }
 __device__ __forceinline__ int b_pose_first_block(const ImuBatchView& b) { return b.pose.first_block; }
@@ -664,69 +652,187 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
   MC_MARK(pslot + 4);   // other x other
 }
 
-template <class View, bool BUILD>
-__global__ __launch_bounds__(64) void k_group(const View* __restrict__ views, DevCommon dc, const GroupRec* __restrict__ groups,
-                                              int jpart_base) {
-  extern __shared__ double tile[];
-  constexpr int D = TermTraits<View>::D;
-  const int lane = threadIdx.x;
-  const GroupRec gr = groups[blockIdx.x];
-  const View b = views[gr.batch];
-  FpView f = fp_view(dc, gr.fp);
-  const int C = f.C;
-  const int ld = (C + 1) | 1;
-  const int R = gr.term_count * D;
+// ---------------------------------------------------------------------------------------------
+// F2 (ReprojectionError with camera design variables over a static chain: the camera-calibration problems).
+// One 256-thread workgroup per RUN of consecutive observations (one camera's view of the target) of one camera.
+//   build: thread = residual ROW (two threads per corner); the weighted row goes to LDS in a fixed "core" column order
+//          [q_t_c 3 | t_t_c 3 | baselines 6 n_chain | projection | distortion | residual]  (<= 41 columns),
+//          the core Gram R^T R is formed on the fp64 matrix cores (16 x 16 tiles, K-steps split over the 4 waves,
+//          per-wave partial tiles summed by LDS atomics), and is then split in two:
+//            - entries that involve the target pose of this observation are flushed at once,
+//            - everything else (baselines x intrinsics ... of this camera) is shared by ALL observations of the camera:
+//              it is summed in registers over the run and flushed once per run -- without that every observation would
+//              queue its atomics on the same few hundred addresses.
+//   evaluate: thread = corner.
+// Pre-pass, one LANE per observation: target pose, baseline chain and intrinsics the corners of the observation share
+// (k_static reads the record back from LDS by broadcast instead of every lane recomputing ~130 registers' worth).
+__global__ __launch_bounds__(64) void k_static_common(const StaticReprojBatchView* __restrict__ views, const double* __restrict__ x,
+                                                      const GroupRec* __restrict__ groups, int n, F2Common* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const GroupRec gr = groups[g];
+  F2Common cm;
+  f2_common(views[gr.batch], x, gr.aux, cm);
+  out[g] = cm;
+}
+enum { F2_MAXCORE = 6 + 6 * F2_MAX_CHAIN + 6 + 4 + 1, F2_NE = (F2_MAXCORE * (F2_MAXCORE + 1) / 2 + 255) / 256 };
+template <bool BUILD>
+__global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticReprojBatchView* __restrict__ views, DevCommon dc,
+                                                const GroupRec* __restrict__ groups, const ImageRec* __restrict__ runs,
+                                                const F2Common* __restrict__ common, int ld, int jpart_base) {
+  extern __shared__ double rows[];   // build: 256 x ld
+  __shared__ F2Common cm;
+  static_assert(sizeof(F2Common) % 8 == 0 && sizeof(F2Common) / 8 <= 256, "F2Common is copied as doubles, one per thread");
+  __shared__ double gram[6 * 256];   // upper tile pairs, [tile][reg][lane] = the MFMA C/D layout
+  __shared__ int crole[F2_MAXCORE], cdim[F2_MAXCORE], lcol[F2_MAXCORE];
+  __shared__ double red[4];
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  const ImageRec run = runs[blockIdx.x];
+  const StaticReprojBatchView b = views[groups[run.first].batch];
+  const int nch = b.n_chain, pd = b.cam.proj_dim, nd = b.cam.dist_off >= 0 ? 4 : 0;
+  const int ncore = 6 + 6 * nch + pd + nd + 1, ecol = ncore - 1;
+  const int nt = (ncore + 15) >> 4, ntile = nt * (nt + 1) / 2;
+  const int E = ncore * (ncore + 1) / 2;
+  int ea[F2_NE], eb[F2_NE];
+  double shared_acc[F2_NE];
   if (BUILD) {
-    for (int i = lane; i < R * ld; i += 64) tile[i] = 0.0;
-    __syncthreads();
-  }
-  double Jacc = 0.0;
-  if (lane < gr.term_count) {
-    const int term = gr.term_first + lane;
-    double e[D];
-    TermOut out;
-    int st = 0;
-    double* Jrow = tile + (size_t)(lane * D) * ld;
-    bool ok = TermTraits<View>::eval(b, dc.x, term, dc.useM != 0, BUILD, f, Jrow, ld, e, out, &st);
-    if (ok) {
-      Jacc = out.w * out.chi2;
-      dc.chi2[b.term_base_global + term] = out.chi2;
+    if (tid < ecol) {
+      int role, d;
+      if (tid < 3) { role = F2_ROLE_QTC; d = tid; }
+      else if (tid < 6) { role = F2_ROLE_TTC; d = tid - 3; }
+      else if (tid < 6 + 6 * nch) { const int j = (tid - 6) / 6, k = (tid - 6) - 6 * j; role = F2_ROLE_CHAIN + 2 * j + (k >= 3 ? 1 : 0); d = k >= 3 ? k - 3 : k; }
+      else if (tid < 6 + 6 * nch + pd) { role = F2_ROLE_PROJ; d = tid - (6 + 6 * nch); }
+      else { role = F2_ROLE_DIST; d = tid - (6 + 6 * nch + pd); }
+      crole[tid] = role; cdim[tid] = d;
+    }
 #pragma unroll
-      for (int r = 0; r < D; ++r) {
-        if (dc.e) dc.e[b.row_base + D * term + r] = -e[r];
-        if (BUILD) Jrow[r * ld + C] = e[r];
+    for (int j = 0; j < F2_NE; ++j) {   // entry idx -> (a <= b) of the upper triangle, idx = b(b+1)/2 + a
+      const int idx = tid + 256 * j;
+      int bb = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+      while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
+      while (bb * (bb + 1) / 2 > idx) --bb;
+      ea[j] = idx - bb * (bb + 1) / 2; eb[j] = bb;
+      shared_acc[j] = 0.0;
+    }
+  }
+  constexpr int CPP = BUILD ? 128 : 256;   // corners per pass
+  const int r = BUILD ? (tid & 1) : 0;
+  const int lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
+  double Jacc = 0.0;
+  int last_fp = -1;
+  for (int go = 0; go < run.count; ++go) {
+    const GroupRec gr = groups[run.first + go];
+    FpView f = fp_view(dc, gr.fp);
+    int rc[MC_MAX_ROLES];
+#pragma unroll
+    for (int q = 0; q < MC_MAX_ROLES; ++q) rc[q] = -1;
+    __syncthreads();   // the previous observation is done with cm / lcol / gram (and crole / cdim are published)
+    if (tid < (int)(sizeof(F2Common) / 8)) reinterpret_cast<double*>(&cm)[tid] = reinterpret_cast<const double*>(common + run.first + go)[tid];
+    if (BUILD) {
+      if (tid < ecol) { const int c0 = f.rolecol[crole[tid]]; lcol[tid] = c0 >= 0 ? c0 + cdim[tid] : -1; }
+      for (int i = tid; i < ntile * 256; i += 256) gram[i] = 0.0;
+      if (f.rolecol[F2_ROLE_QTC] >= 0) rc[F2_ROLE_QTC] = 0;
+      if (f.rolecol[F2_ROLE_TTC] >= 0) rc[F2_ROLE_TTC] = 3;
+#pragma unroll
+      for (int j = 0; j < F2_MAX_CHAIN; ++j) {
+        if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j] >= 0) rc[F2_ROLE_CHAIN + 2 * j] = 6 + 6 * j;
+        if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j + 1] >= 0) rc[F2_ROLE_CHAIN + 2 * j + 1] = 9 + 6 * j;
       }
-    } else {
-      atomicOr(dc.status, st);
+      if (f.rolecol[F2_ROLE_PROJ] >= 0) rc[F2_ROLE_PROJ] = 6 + 6 * nch;
+      if (nd && f.rolecol[F2_ROLE_DIST] >= 0) rc[F2_ROLE_DIST] = 6 + 6 * nch + pd;
+    }
+    __syncthreads();
+    f64x4 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < gr.term_count; base += CPP) {
+      const int k = base + (BUILD ? (tid >> 1) : tid);
+      const int nrows = 2 * min(CPP, gr.term_count - base);
+      if (k < gr.term_count) {
+        const int term = gr.term_first + k;
+        double e[2];
+        TermOut out;
+        double* row = rows + tid * ld;
+        // the inactive roles' columns keep whatever the tile held: their Gram entries are never flushed
+        f2_term_cm(b, cm, term, dc.useM != 0, BUILD, rc, BUILD ? row - r * ld : nullptr, ld, e, out, BUILD ? (1 << r) : 3);
+        if (r == 0) { Jacc += out.w * out.chi2; dc.chi2[b.term_base_global + term] = out.chi2; }
+        if (dc.e) {
+          if (BUILD) dc.e[b.row_base + 2 * term + r] = -e[r];
+          else { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
+        }
+        if (BUILD) row[ecol] = e[r];
+      }
+      if (BUILD) {
+        __syncthreads();
+        const int nsteps = (nrows + 3) >> 2;
+        for (int st = tid >> 6; st < nsteps; st += 4) {
+          const int rr = 4 * st + kr;
+          double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+          if (rr < nrows) {
+            const double* rp = rows + rr * ld + c16;
+            if (c16 < ncore) v0 = rp[0];
+            if (16 + c16 < ncore) v1 = rp[16];
+            if (32 + c16 < ncore) v2 = rp[32];
+          }
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc[0], 0, 0, 0);
+          if (nt > 1) {
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc[2], 0, 0, 0);
+          }
+          if (nt > 2) {
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v2, acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v2, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc[5], 0, 0, 0);
+          }
+        }
+        __syncthreads();   // the row tile is rewritten by the next pass
+      }
+    }
+    if (BUILD) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        if (t < ntile) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) atomicAdd(&gram[(t * 4 + rg) * 64 + lane], acc[t][rg]);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < F2_NE; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx >= E || ea[j] == ecol) continue;
+        const int a = ea[j], bq = eb[j];
+        const int ta = a >> 4, tb = bq >> 4, i = a & 15, jj = bq & 15;
+        const double m = gram[((tb * (tb + 1) / 2 + ta) * 4 + (i >> 2)) * 64 + (i & 3) * 16 + jj];
+        if (a >= 6) { shared_acc[j] += m; continue; }
+        const int la = lcol[a];
+        if (la < 0) continue;
+        if (bq == ecol) { atomic_add_f64(dc.rhs + global_col(f, la), -m); continue; }
+        const int lb = lcol[bq];
+        if (lb < 0) continue;
+        atomic_add_f64(dc.Cx + entry_addr(f, dc.col_h, min(la, lb), max(la, lb)), m);
+      }
+      last_fp = gr.fp;
     }
   }
   Jacc = wave_sum(Jacc);
-  if (lane == 0) dc.Jpart[jpart_base + blockIdx.x] = Jacc;
-  if (!BUILD) return;
+  if (lane == 0) red[tid >> 6] = Jacc;
   __syncthreads();
-  if (MC_MODE(dc) == 3) return;
-  if (MC_MODE(dc) == 2) {
-    double tot = 0.0;
-    for (int cb = 0; cb < C; ++cb)
-      for (int ca = lane; ca <= cb; ca += 64) {
-        double s = 0.0;
-        for (int r = 0; r < R; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
-        tot += s;
-      }
-    if (tot == 1.2345e-300) dc.rhs[0] = tot;
-    return;
-  }
-  for (int cb = 0; cb < C; ++cb) {
-    for (int ca = lane; ca <= cb; ca += 64) {
-      double s = 0.0;
-      for (int r = 0; r < R; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
-      if (s != 0.0) atomic_add_f64(dc.Cx + entry_addr(f, dc.col_h, ca, cb), s);
-    }
-  }
-  for (int ca = lane; ca < C; ca += 64) {
-    double s = 0.0;
-    for (int r = 0; r < R; ++r) s += tile[r * ld + ca] * tile[r * ld + C];
-    if (s != 0.0) atomic_add_f64(dc.rhs + global_col(f, ca), -s);
+  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (!BUILD || last_fp < 0) return;
+  // camera-level part, through the last observation's footprint (same camera: same baseline / intrinsics blocks)
+  FpView f = fp_view(dc, last_fp);
+#pragma unroll
+  for (int j = 0; j < F2_NE; ++j) {
+    const int idx = tid + 256 * j;
+    if (idx >= E || ea[j] == ecol || ea[j] < 6) continue;
+    const int la = lcol[ea[j]];
+    if (la < 0) continue;
+    const double m = shared_acc[j];
+    if (eb[j] == ecol) { atomic_add_f64(dc.rhs + global_col(f, la), -m); continue; }
+    const int lb = lcol[eb[j]];
+    if (lb < 0) continue;
+    atomic_add_f64(dc.Cx + entry_addr(f, dc.col_h, min(la, lb), max(la, lb)), m);
   }
 }
 
@@ -1036,9 +1142,11 @@ struct LaunchUnit {
   DevBuf<StreamBatch<LidarBatchView>> lviews;
   DevBuf<StreamBatch<ImuSmBatchView>> xviews;
   DevBuf<MotionView> mviews;
+  DevBuf<F2Common> common2;  // F2: per observation, rewritten by k_static_common before every k_static
   DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
-  DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time
+  DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time; F2: runs of observations of one camera
   int n_images = 0;
+  int static_ld = 0;         // F2: row stride of the LDS tile
 };
 
 }  // namespace mc
@@ -1157,7 +1265,11 @@ void mc_context::uploadStructure() {
   std::vector<StreamBatch<LidarBatchView>> lviews;
   std::vector<StreamBatch<ImuSmBatchView>> xviews;
   std::vector<MotionView> mviews;
-  std::vector<ImageRec> images;
+  std::vector<ImageRec> images, static_runs;
+  // F2: observations per workgroup -- enough workgroups to fill the chip first, then longer runs (fewer camera-level flushes)
+  int n_static_obs = 0;
+  for (const Batch& b : P.batches) if (b.kind == KIND_STATIC_REPROJ) n_static_obs += (int)b.my_groups.size();
+  const int static_run = std::min(8, std::max(1, n_static_obs / 1024));
   for (int l = 0; l < N_LAUNCH; ++l) lu[l] = LaunchUnit();
   int term_base = 0;
   for (Batch& b : P.batches) {
@@ -1182,12 +1294,16 @@ void mc_context::uploadStructure() {
       dm.maxNob = std::max(dm.maxNob, b.max_nob); dm.maxG = std::max(dm.maxG, b.max_g);
       dm.maxTab = std::max(dm.maxTab, b.max_tab);
     } else if (b.kind != KIND_MOTION) {
-      int maxR = 0, maxC = 0;
       double last_time = 0;
       bool first_of_batch = true;
       for (GroupRec g : b.my_groups) {
         if (g.term_count == 0) continue;
         g.batch = view_index;
+        if (b.kind == KIND_STATIC_REPROJ) {
+          if (first_of_batch || static_runs.back().count >= static_run) static_runs.push_back(ImageRec{(int)groups[li].size(), 0});
+          static_runs.back().count++;
+          first_of_batch = false;
+        }
         if (b.kind == KIND_REPROJ) {
           // observations of one camera at one time form an image (they share everything but the board pose)
           double tg = b.t[g.aux];
@@ -1196,11 +1312,13 @@ void mc_context::uploadStructure() {
           last_time = tg; first_of_batch = false;
         }
         groups[li].push_back(g);
-        maxR = std::max(maxR, g.term_count * b.dim); maxC = std::max(maxC, P.fp_data[P.fp_off[g.fp] + 1]);
       }
       if (b.kind == KIND_STATIC_REPROJ) {
-        L.lds_bytes = std::max(L.lds_bytes, maxR * ((maxC + 1) | 1) * (int)sizeof(double));
-        if (L.lds_bytes > 64 * 1024) throw std::runtime_error("group tile exceeds the LDS budget");
+        if ((int)b.chain_q.size() > F2_MAX_CHAIN) throw std::runtime_error("camera chain longer than F2_MAX_CHAIN");
+        const CameraRec& c = P.cams[b.cam];
+        const int ncore = 6 + 6 * (int)b.chain_q.size() + P.dvs[c.dv_proj].dim + (c.dv_dist >= 0 ? 4 : 0) + 1;
+        L.static_ld = std::max(L.static_ld, ncore | 1);   // odd stride: conflict-free row writes and column reads
+        L.lds_bytes = 256 * L.static_ld * (int)sizeof(double);
       }
     }
     d->sinv.upload(b.sinv);
@@ -1340,6 +1458,13 @@ void mc_context::uploadStructure() {
         L.images.upload(images);
         L.n_images = (int)images.size();
         L.n_jpart = L.n_images;
+      } else {
+        L.common2.alloc(groups[l].size());
+        L.images.upload(static_runs);
+        L.n_images = (int)static_runs.size();
+        L.n_jpart = L.n_images;
+        if (L.lds_bytes > 64 * 1024)
+          HIP_CHECK(hipFuncSetAttribute((const void*)k_static<true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
       }
     }
     n_jpart += L.n_jpart;
@@ -1392,8 +1517,9 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
         else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
         break;
       case LAUNCH_STATIC:
-        if (build) hipLaunchKernelGGL((k_group<StaticReprojBatchView, true>), dim3(L.n_items), dim3(64), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.jpart_base);
-        else hipLaunchKernelGGL((k_group<StaticReprojBatchView, false>), dim3(L.n_items), dim3(64), 0, st, L.sviews.p, dc, L.groups.p, L.jpart_base);
+        hipLaunchKernelGGL(k_static_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.sviews.p, x.p, L.groups.p, L.n_items, L.common2.p);
+        if (build) hipLaunchKernelGGL(k_static<true>, dim3(L.n_images), dim3(256), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.images.p, L.common2.p, L.static_ld, L.jpart_base);
+        else hipLaunchKernelGGL(k_static<false>, dim3(L.n_images), dim3(256), 0, st, L.sviews.p, dc, L.groups.p, L.images.p, L.common2.p, L.static_ld, L.jpart_base);
         break;
       case LAUNCH_IMU:
         if (build) hipLaunchKernelGGL((k_stream<ImuBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
@@ -1713,7 +1839,7 @@ int mc_launch_info(const mc_context* ctx, int launch, int* n_batches, int* n_ter
   const LaunchUnit& L = ctx->lu[launch];
   if (n_batches) *n_batches = L.n_batches;
   if (n_terms) *n_terms = L.n_terms;
-  if (n_workgroups) *n_workgroups = launch == LAUNCH_MOTION ? L.n_items * L.motion_blocks : (launch == LAUNCH_REPROJ ? L.n_images : L.n_items);
+  if (n_workgroups) *n_workgroups = launch == LAUNCH_MOTION ? L.n_items * L.motion_blocks : ((launch == LAUNCH_REPROJ || launch == LAUNCH_STATIC) ? L.n_images : L.n_items);
   return 0;
 }
 int mc_launch_counts(const mc_context* ctx, int launch, double* flops_dense, double* flops_live, double* record_bytes) {

@@ -767,28 +767,53 @@ struct StaticReprojBatchView {
   int mest; double mest_a;
   int n_obs, n_terms, row_base, term_base_global;
 };
-MC_HD bool f2_term(const StaticReprojBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
-                   double* J, int ld, double* e, TermOut& out) {
-  int obs = b.term_obs[k];
-  Rigid Ttc, T;
+// what every corner of one observation (one camera's view of the target) shares
+struct F2Common {
+  Rigid Tinv;               // inverse(T_t_c)
+  Rigid T;                  // B_{n-1} ... B_0 inverse(T_t_c)
+  Rigid Bj[F2_MAX_CHAIN];   // the baselines
+  double rtc[3];            // translation of T_t_c
+  double pp[6], dk[4];      // projection / distortion parameters
+};
+// loops over the chain are unrolled to F2_MAX_CHAIN with a guard so that every array index is a compile-time
+// constant (a run-time bound would put the temporaries into scratch memory on the GPU)
+MC_HD void f2_common(const StaticReprojBatchView& b, const double* x, int obs, F2Common& cm) {
+  Rigid Ttc;
   load_rigid(x, b.obs_qtc_off[obs], b.obs_ttc_off[obs], Ttc);
-  rigid_inv(Ttc, T);  // T_c0_t
-  Rigid Tinv = T;     // inverse(T_t_c), kept for the leaf chain
-  Rigid pre[F2_MAX_CHAIN];  // pre[j] = transform to the right of baseline j (before multiplying B_j)
-  Rigid Bj[F2_MAX_CHAIN];
-  for (int j = 0; j < b.n_chain; ++j) {
-    pre[j] = T;
-    load_rigid(x, b.chain_q[j].off, b.chain_t[j].off, Bj[j]);
-    Rigid N;
-    rigid_mul(Bj[j], T, N);
-    T = N;
+  cm.rtc[0] = Ttc.r[0]; cm.rtc[1] = Ttc.r[1]; cm.rtc[2] = Ttc.r[2];
+  rigid_inv(Ttc, cm.Tinv);  // T_c0_t
+  Rigid T = cm.Tinv;
+#pragma unroll
+  for (int j = 0; j < F2_MAX_CHAIN; ++j) {
+    if (j < b.n_chain) {
+      load_rigid(x, b.chain_q[j].off, b.chain_t[j].off, cm.Bj[j]);
+      Rigid N;
+      rigid_mul(cm.Bj[j], T, N);
+      T = N;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cm.Bj[j].C[i] = 0.0;
+      cm.Bj[j].r[0] = cm.Bj[j].r[1] = cm.Bj[j].r[2] = 0.0;
+    }
   }
+  cm.T = T;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) cm.pp[i] = i < b.cam.proj_dim ? x[b.cam.proj_off + i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cm.dk[i] = b.cam.dist_off >= 0 ? x[b.cam.dist_off + i] : 0.0;
+}
+// rmask: bit r set = write Jacobian row r (to J + r * ld); the row-per-thread kernel asks for one row only
+MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, int k, bool useM, bool wantJ, const int* rolecol,
+                      double* J, int ld, double* e, TermOut& out, int rmask = 3) {
+  const Rigid& T = cm.T;
+  const Rigid& Tinv = cm.Tinv;
+  const Rigid* Bj = cm.Bj;
+  const double* pp = cm.pp;
+  const double* dk = cm.dk;
   const double* pt = b.p + 3 * (size_t)k;
   double pc[3];
   m3_mulv(T.C, pt, pc);
   pc[0] += T.r[0]; pc[1] += T.r[1]; pc[2] += T.r[2];
-  const double* pp = x + b.cam.proj_off;
-  const double* dk = b.cam.dist_off >= 0 ? x + b.cam.dist_off : x;
   double kp[2], Jc[6];
   project(b.cam.model, b.cam.dist, pp, dk, pc, kp, wantJ ? Jc : nullptr);
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
@@ -801,37 +826,57 @@ MC_HD bool f2_term(const StaticReprojBatchView& b, const double* x, int k, bool 
   double Ji[12], Jd[8];
   if (rolecol[F2_ROLE_PROJ] >= 0) intrinsics_jacobian(b.cam.model, b.cam.dist, pp, dk, pc, Ji);
   if (rolecol[F2_ROLE_DIST] >= 0) distortion_jacobian(b.cam.model, b.cam.dist, pp, pc, Jd);
+  const int pd = b.cam.proj_dim;
+#pragma unroll
   for (int r = 0; r < 2; ++r) {
+    if (!((rmask >> r) & 1)) continue;
     double* row = J + r * ld;
     double a[3] = {-sw * Jc[3 * r], -sw * Jc[3 * r + 1], -sw * Jc[3 * r + 2]};
     double u[3] = {a[0], a[1], a[2]}, v[3];
     v3_cross(a, pc, v);
     // top-down through Multiply(B_j, rest): lhs gets the chain, rhs gets chain * boxTimes(B_j)
-    for (int j = b.n_chain - 1; j >= 0; --j) {
-      double Jq[3], Jt[3];
-      chain_basic(u, v, Bj[j].r, Jq, Jt);
-      int cq = rolecol[F2_ROLE_CHAIN + 2 * j], ct = rolecol[F2_ROLE_CHAIN + 2 * j + 1];
-      if (cq >= 0) for (int c = 0; c < 3; ++c) row[cq + c] = Jq[c] * b.chain_q[j].scale;
-      if (ct >= 0) for (int c = 0; c < 3; ++c) row[ct + c] = Jt[c] * b.chain_t[j].scale;
-      double u2[3], v2[3];
-      chain_boxtimes(u, v, Bj[j], u2, v2);
-      u[0] = u2[0]; u[1] = u2[1]; u[2] = u2[2]; v[0] = v2[0]; v[1] = v2[1]; v[2] = v2[2];
+#pragma unroll
+    for (int jj = 0; jj < F2_MAX_CHAIN; ++jj) {
+      const int j = F2_MAX_CHAIN - 1 - jj;
+      if (j < b.n_chain) {
+        double Jq[3], Jt[3];
+        chain_basic(u, v, Bj[j].r, Jq, Jt);
+        int cq = rolecol[F2_ROLE_CHAIN + 2 * j], ct = rolecol[F2_ROLE_CHAIN + 2 * j + 1];
+        if (cq >= 0) for (int c = 0; c < 3; ++c) row[cq + c] = Jq[c] * b.chain_q[j].scale;
+        if (ct >= 0) for (int c = 0; c < 3; ++c) row[ct + c] = Jt[c] * b.chain_t[j].scale;
+        double u2[3], v2[3];
+        chain_boxtimes(u, v, Bj[j], u2, v2);
+        u[0] = u2[0]; u[1] = u2[1]; u[2] = u2[2]; v[0] = v2[0]; v[1] = v2[1]; v[2] = v2[2];
+      }
     }
     // inverse node: chain * (-boxTimes(inverse(T_t_c)))
     double u2[3], v2[3], Jq[3], Jt[3];
     chain_boxtimes(u, v, Tinv, u2, v2);
     u2[0] = -u2[0]; u2[1] = -u2[1]; u2[2] = -u2[2]; v2[0] = -v2[0]; v2[1] = -v2[1]; v2[2] = -v2[2];
-    chain_basic(u2, v2, Ttc.r, Jq, Jt);
+    chain_basic(u2, v2, cm.rtc, Jq, Jt);
     if (rolecol[F2_ROLE_QTC] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[F2_ROLE_QTC] + c] = Jq[c] * b.qtc_scale;
     if (rolecol[F2_ROLE_TTC] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[F2_ROLE_TTC] + c] = Jt[c] * b.ttc_scale;
-    // camera design variables: -Jp, -Jd   (CameraDesignVariable.hpp:45-52)
-    if (rolecol[F2_ROLE_PROJ] >= 0)
-      for (int c = 0; c < b.cam.proj_dim; ++c) row[rolecol[F2_ROLE_PROJ] + c] = -sw * b.proj_scale * Ji[r * b.cam.proj_dim + c];
+    // camera design variables: -Jp, -Jd   (CameraDesignVariable.hpp:45-52); Ji is 2 x proj_dim, row-major
+    if (rolecol[F2_ROLE_PROJ] >= 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double jv;
+        if (pd == 4) jv = c < 4 ? Ji[r * 4 + (c & 3)] : 0.0;
+        else if (pd == 5) jv = c < 5 ? Ji[r * 5 + (c < 5 ? c : 0)] : 0.0;
+        else jv = Ji[r * 6 + c];
+        if (c < pd) row[rolecol[F2_ROLE_PROJ] + c] = -sw * b.proj_scale * jv;
+      }
+    }
     if (rolecol[F2_ROLE_DIST] >= 0)
       for (int c = 0; c < 4; ++c) row[rolecol[F2_ROLE_DIST] + c] = -sw * b.dist_scale * Jd[r * 4 + c];
   }
-  (void)pre;
   return true;
+}
+MC_HD bool f2_term(const StaticReprojBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
+                   double* J, int ld, double* e, TermOut& out, int rmask = 3) {
+  F2Common cm;
+  f2_common(b, x, b.term_obs[k], cm);
+  return f2_term_cm(b, cm, k, useM, wantJ, rolecol, J, ld, e, out, rmask);
 }
 
 }  // namespace mc
