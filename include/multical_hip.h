@@ -160,6 +160,13 @@ int mc_build_system(mc_context* ctx, int use_mestimator, double* Cx_out, double*
  * are zeroed by the call.  With shards, the caller sums d_J/d_Cx/d_rhs over ranks (RCCL all-reduce). */
 int mc_evaluate_error_device(mc_context* ctx, int use_mestimator, double* d_J, double* d_e, void* stream);
 int mc_build_system_device(mc_context* ctx, int use_mestimator, double* d_Cx, double* d_rhs, void* stream);
+/* Both in ONE pass over the terms.  Optimizer2::optimize (Optimizer2.cpp:183-275) calls evaluateError at the updated state
+ * and, when the step is accepted, buildSystem at that same state in the next iteration; the build kernels already form
+ * every residual, so a caller that builds speculatively (into a second value buffer: a rejected Levenberg-Marquardt step
+ * keeps the previous system, LevenbergMarquardtTrustRegionPolicy.cpp:61-72) gets J, e, Cx and rhs from one set of
+ * launches.  Results are those of the two calls above made one after the other.  d_e may be NULL. */
+int mc_evaluate_error_and_build_system_device(mc_context* ctx, int use_mestimator, double* d_J, double* d_e, double* d_Cx,
+                                              double* d_rhs, void* stream);
 /* ---- second backend: J^T for SparseCholeskyLinearSystemSolver -------------------------------------------------
  * SparseCholeskyLinearSystemSolver::initMatrixStructureImplementation / buildSystem
  * (aslam_backend/src/SparseCholeskyLinearSystemSolver.cpp:15-45) keep the Jacobian itself: J^T (j_cols x j_rows) in

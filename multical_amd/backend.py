@@ -202,6 +202,9 @@ class HipApi(object):
     def evaluate_error_device(self, use_mest, d_J, d_e, stream):
         self._chk(self.lib.mc_evaluate_error_device(self.ctx, int(use_mest), d_J, d_e, stream))
 
+    def evaluate_error_and_build_system_device(self, use_mest, d_J, d_e, d_Cx, d_rhs, stream):
+        self._chk(self.lib.mc_evaluate_error_and_build_system_device(self.ctx, int(use_mest), d_J, d_e, d_Cx, d_rhs, stream))
+
     def build_system_device(self, use_mest, d_Cx, d_rhs, stream):
         self._chk(self.lib.mc_build_system_device(self.ctx, int(use_mest), d_Cx, d_rhs, stream))
 

@@ -1754,6 +1754,15 @@ int mc_build_system_device(mc_context* ctx, int use_mestimator, double* d_Cx, do
   return 0;
   MC_CATCH(ctx, -1)
 }
+int mc_evaluate_error_and_build_system_device(mc_context* ctx, int use_mestimator, double* d_J, double* d_e, double* d_Cx,
+                                              double* d_rhs, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  if (!d_J || !d_Cx || !d_rhs) throw std::invalid_argument("d_J, d_Cx and d_rhs are required");
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->launchAll(true, use_mestimator, d_Cx, d_rhs, d_J, d_e, (hipStream_t)stream);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
 int mc_evaluate_error(mc_context* ctx, int use_mestimator, double* J_out, double* e_out) {
   MC_TRY MC_NEED_FINAL(ctx);
   HIP_CHECK(hipSetDevice(ctx->device));

@@ -198,6 +198,28 @@ def test_device_pointer_entry_points(hip_small):
     assert np.array_equal(de.cpu().numpy(), e)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_mest", [True, False])
+def test_fused_evaluate_and_build_equals_the_two_calls(hip_small, use_mest):
+    """mc_evaluate_error_and_build_system_device: J, e, Cx, rhs of one pass = evaluateError followed by buildSystem."""
+    import torch
+    g, _ = hip_small
+    Cx, rhs = g.build_system(use_mest)
+    J, e = g.evaluate_error(use_mest)
+    dCx = torch.full((g.nnz,), 7.0, dtype=torch.float64, device="cuda:0")
+    drhs = torch.full((g.j_cols,), 7.0, dtype=torch.float64, device="cuda:0")
+    dJ = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    de = torch.zeros(g.j_rows, dtype=torch.float64, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    g.evaluate_error_and_build_system_device(use_mest, dJ.data_ptr(), de.data_ptr(), dCx.data_ptr(), drhs.data_ptr(), st)
+    torch.cuda.synchronize()
+    g.check_status()
+    _close(dCx.cpu().numpy(), Cx, 1e-12)
+    _close(drhs.cpu().numpy(), rhs, 1e-12)
+    assert abs(dJ.item() - J) <= 1e-12 * J
+    assert np.array_equal(de.cpu().numpy(), e)
+
+
 def test_time_offset_buffer_exceeded_is_reported(small_problem):
     """TransformationTimeOffsetExpressionNode throws 'Spline Coefficient Buffer Exceeded' when the time offset leaves the
     frozen buffer (BSplineExpressions.cpp:447, 503)."""
