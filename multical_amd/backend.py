@@ -282,7 +282,7 @@ class HipApi(object):
     def unpack_shared(self, d_buf, d_cx, stream=None):
         self._chk(self.lib.mc_unpack_shared(self.ctx, C.c_void_p(d_buf), C.c_void_p(d_cx), C.c_void_p(stream or 0)))
 
-    LAUNCH_NAMES = ("k_reproj", "k_group<StaticReproj>", "k_stream<Imu>", "k_stream<Lidar>", "k_motion", "k_stream<ImuSm>")
+    LAUNCH_NAMES = ("k_reproj", "k_static", "k_stream<Imu>", "k_stream<Lidar>", "k_motion", "k_stream<ImuSm>")
 
     def launch_info(self):
         """[(kernel name, batches, terms, workgroups, flops_dense, flops_live, record_bytes)] per kernel launch of a build"""

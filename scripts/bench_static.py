@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """evaluateError + buildSystem timing of the static camera-calibration problems (BASELINE configs[0] and configs[2],
-ReprojectionError with intrinsics: kernel k_group<StaticReproj>) and of the J^T backend the reference's default solver
+ReprojectionError with intrinsics: kernel k_static) and of the J^T backend the reference's default solver
 uses on them.  Not the bench line (bench.py measures configs[3]); numbers go to DESIGN.md.
 
     python scripts/bench_static.py 2

@@ -12,6 +12,8 @@ tag = sys.argv[1]
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join("profiles", tag + "_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "trace_serial", "trace_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "trace_serial", "trace_kernel_stats.csv"), os.path.join("profiles", tag + "_kernel_stats_serial_launch.csv"))
 with open(os.path.join(src, "bench_trace.log")) as f:
     lines = [l for l in f if l.startswith("{")]
 with open(os.path.join("profiles", tag + "_bench_under_rocprof.json"), "w") as f:
@@ -40,7 +42,7 @@ print(open(os.path.join("profiles", tag + "_pmc_hbm_traffic.csv")).read())
 # per-launch HBM bytes (fetch x2 + write) of the buildSystem kernels, for bench.py's roofline.traffic
 import json
 short = {"k_reproj<true>": "k_reproj", "k_stream<mc::ImuBatchView, true>": "k_stream<Imu>", "k_stream<mc::LidarBatchView, true>": "k_stream<Lidar>",
-         "k_motion(": "k_motion", "k_group<mc::StaticReprojBatchView, true>": "k_group<StaticReproj>"}
+         "k_motion(": "k_motion", "k_static<true>": "k_static"}
 out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline", "unit": "bytes per launch", "kernels": {}}
 for k, a in agg.items():
     for pat, name in short.items():
