@@ -87,6 +87,21 @@ int mc_add_static_reprojection_batch(mc_context* ctx, int camera, int n_chain, c
                                      const int* obs_dv_t_t_c, const int* obs_first, const double* y,
                                      const double* p_target, const double* sqrt_inv_r, int mest_kind,
                                      double mest_param);
+/* The front-end's initialisation problems (small; a handful of global design variables, no spline).
+ * kalibr GyroscopeError(measurement, invR, angularVelocity, bias) (kalibr/src/GyroscopeError.cpp:5-17) as
+ * findExtrinsicPriorSensorsToCamera builds it (kalibr_sensor_calibration/sensors_and_targets.py:858-879):
+ * e = C(q) * w_pred + bias - meas with w_pred a constant per term; dv_q ROTATION_QUATERNION, dv_bias EUCLIDEAN_POINT. */
+int mc_add_gyroscope_prior_batch(mc_context* ctx, int dv_q, int dv_bias, int n, const double* w_pred /* [n,3] */,
+                                 const double* meas /* [n,3] */, const double* sqrt_inv_r /* [n] */, int mest_kind,
+                                 double mest_param);
+/* aslam::backend::ErrorTermTransformation(T, prior, weightRotation, weightTranslation)
+ * (aslam_backend_expressions/src/ErrorTermTransformation.cpp:19-81) with T = TransformationBasic(q_a, t_a) or, when
+ * dv_q_b / dv_t_b >= 0, T = TransformationBasic(q_a, t_a) * inverse(TransformationBasic(q_b, t_b))
+ * (findTargetPosePrior / findExtrinsicPriorSensorsToCamera, sensors_and_targets.py:812-817, 886-919).
+ * prior_q [n,4] quaternions [x y z w], prior_t [n,3]. */
+int mc_add_transformation_batch(mc_context* ctx, int dv_q_a, int dv_t_a, int dv_q_b, int dv_t_b, int n,
+                                const double* prior_q, const double* prior_t, double weight_rotation,
+                                double weight_translation, int mest_kind, double mest_param);
 /* kalibr EuclideanError, accelerometer form (sensors_and_targets.py:1133-1179; kalibr/src/EuclideanError.cpp:5-27).
  * bias_spline < 0: static bias dv_bias.  dv_gravity: EUCLIDEAN_DIRECTION or EUCLIDEAN_POINT. */
 int mc_add_accelerometer_batch(mc_context* ctx, int pose_spline, int bias_spline, int dv_bias, int dv_gravity,

@@ -31,6 +31,9 @@ SIGNATURES = {
                                              _dp, C.c_int, C.c_double]),
     "mc_add_gyroscope_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int,
                                          C.c_double]),
+    "mc_add_gyroscope_prior_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double]),
+    "mc_add_transformation_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
+                                              C.c_int, C.c_double]),
     "mc_add_matrix_design_variable": (C.c_int, [_ctx, _dp, _ip, C.c_int, C.c_double]),
     "mc_add_accelerometer_batch_sm": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int,
                                                 _dp, _dp, _dp, C.c_int, C.c_double]),

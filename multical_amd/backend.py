@@ -112,6 +112,20 @@ class HipApi(object):
         self._chk(self.lib.mc_add_gyroscope_batch(self.ctx, pose_spline, bias_spline, dv_bias, dv_q_ib, t.size, _dp(t), _dp(meas),
                                                   _dp(sinv), mest, float(mest_param)))
 
+    def add_gyroscope_prior_batch(self, dv_q, dv_bias, w_pred, meas, sinv, mest=0, mest_param=0.0):
+        w_pred, meas, sinv = _f64(w_pred), _f64(meas), _f64(sinv)
+        assert w_pred.size == 3 * sinv.size and meas.size == 3 * sinv.size
+        self._chk(self.lib.mc_add_gyroscope_prior_batch(self.ctx, dv_q, dv_bias, sinv.size, _dp(w_pred), _dp(meas), _dp(sinv), mest,
+                                                        float(mest_param)))
+
+    def add_transformation_batch(self, dv_q_a, dv_t_a, dv_q_b, dv_t_b, prior_q, prior_t, weight_rotation, weight_translation,
+                                 mest=0, mest_param=0.0):
+        prior_q, prior_t = _f64(prior_q), _f64(prior_t)
+        n = prior_t.size // 3
+        assert prior_q.size == 4 * n and prior_t.size == 3 * n
+        self._chk(self.lib.mc_add_transformation_batch(self.ctx, dv_q_a, dv_t_a, dv_q_b, dv_t_b, n, _dp(prior_q), _dp(prior_t),
+                                                       float(weight_rotation), float(weight_translation), mest, float(mest_param)))
+
     def add_matrix_design_variable(self, A, pattern, active=True, scaling=1.0):
         A, pattern = _f64(A).reshape(9), _i32(pattern).reshape(9)
         return self._chk(self.lib.mc_add_matrix_design_variable(self.ctx, _dp(A), _ip(pattern), int(bool(active)), float(scaling)))
@@ -282,7 +296,8 @@ class HipApi(object):
     def unpack_shared(self, d_buf, d_cx, stream=None):
         self._chk(self.lib.mc_unpack_shared(self.ctx, C.c_void_p(d_buf), C.c_void_p(d_cx), C.c_void_p(stream or 0)))
 
-    LAUNCH_NAMES = ("k_reproj", "k_static", "k_stream<Imu>", "k_stream<Lidar>", "k_motion", "k_stream<ImuSm>")
+    LAUNCH_NAMES = ("k_reproj", "k_static", "k_stream<Imu>", "k_stream<Lidar>", "k_motion", "k_stream<ImuSm>",
+                    "k_small<GyroPrior>", "k_small<Transformation>")
 
     def launch_info(self):
         """[(kernel name, batches, terms, workgroups, flops_dense, flops_live, record_bytes)] per kernel launch of a build"""

@@ -25,7 +25,10 @@ namespace mc {
 enum { DV_EUCLIDEAN_POINT = 0, DV_ROTATION_QUATERNION = 1, DV_SCALAR = 2, DV_EUCLIDEAN_DIRECTION = 3,
        DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6, DV_MATRIX_BASIC = 7 };
 enum { KIND_REPROJ = 0, KIND_STATIC_REPROJ = 1, KIND_ACCEL = 2, KIND_GYRO = 3, KIND_LIDAR = 4, KIND_MOTION = 5,
-       KIND_ACCEL_SM = 6, KIND_GYRO_SM = 7, N_KINDS = 8 };
+       KIND_ACCEL_SM = 6, KIND_GYRO_SM = 7, KIND_GYRO_PRIOR = 8, KIND_TRANSFORMATION = 9, N_KINDS = 10 };
+// terms over a handful of global design variables (the initialisation problems): every term of a batch writes the same blocks
+inline bool kindIsGlobal(int k) { return k == KIND_GYRO_PRIOR || k == KIND_TRANSFORMATION; }
+enum { GLOBAL_GROUP_TERMS = 64 };   // terms per workgroup of the small-problem kernel (64 x 6 rows x 13 columns of LDS)
 inline bool kindIsImu(int k) { return k == KIND_ACCEL || k == KIND_GYRO || k == KIND_ACCEL_SM || k == KIND_GYRO_SM; }
 inline bool kindIsAccel(int k) { return k == KIND_ACCEL || k == KIND_ACCEL_SM; }
 inline bool kindIsStream(int k) { return k == KIND_LIDAR || kindIsImu(k); }
@@ -73,6 +76,7 @@ struct Batch {
   int dv[14] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
   int size_effect = 0;
   double pad = 0;
+  double w_t = 1.0, w_r = 1.0;   // ErrorTermTransformation: translation / rotation weights (diagonal invR)
   // per-term / per-observation host arrays
   std::vector<double> t, y, p, sinv, meas, range;
   std::vector<int> obs_first, obs_dv_q, obs_dv_t, term_dv_q, term_dv_t, term_obs;
@@ -566,6 +570,20 @@ inline void Problem::finalize() {
         ++c_count;
       }
       closeChunk();
+    } else if (kindIsGlobal(b.kind)) {
+      // roles = positions in b.dv (GP_ROLE_* / TE_ROLE_*); one footprint for the whole batch
+      std::vector<int> pattern;
+      std::vector<std::array<int, 3>> written;
+      const int nrole = b.kind == KIND_GYRO_PRIOR ? 2 : 4;
+      for (int r = 0; r < nrole; ++r)
+        if (blk(b.dv[r]) >= 0) { pattern.push_back(blk(b.dv[r])); written.push_back({r, blk(b.dv[r]), 1}); }
+      std::sort(pattern.begin(), pattern.end());
+      if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
+        throw std::invalid_argument("a design variable plays two roles in one error term");
+      int fp = internFootprint(pattern, written);
+      pushGroup(0, b.n_terms, fp, 0, 0.0, (int)GLOBAL_GROUP_TERMS);
+      // terms in order carry the time 'term index' for the shard cut (no time axis in these problems)
+      for (size_t g = 0; g < b.group_time.size(); ++g) b.group_time[g] = (double)b.groups[g].term_first;
     } else if (b.kind == KIND_STATIC_REPROJ) {
       int n_obs = (int)b.obs_first.size() - 1;
       const CameraRec& c = cams[b.cam];

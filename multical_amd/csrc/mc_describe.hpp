@@ -68,6 +68,47 @@ inline void describeStaticReprojection(Problem& P, int cam, int n_chain, const i
   P.batches.push_back(std::move(b));
 }
 
+// GyroscopeError over constants (findExtrinsicPriorSensorsToCamera, sensors_and_targets.py:858-879)
+inline void describeGyroPrior(Problem& P, int dv_q, int dv_bias, int n, const double* w_pred, const double* meas, const double* sinv,
+                              int mest, double mest_a) {
+  requireOpen(P);
+  P.checkDv(dv_q, DV_ROTATION_QUATERNION); P.checkDv(dv_bias, DV_EUCLIDEAN_POINT);
+  checkMest(mest);
+  if (n < 0) throw std::invalid_argument("negative term count");
+  Batch b;
+  b.kind = KIND_GYRO_PRIOR; b.dim = 3; b.n_terms = n; b.mest = mest; b.mest_a = mest_a;
+  b.dv[0] = dv_q; b.dv[1] = dv_bias;
+  b.p.assign(w_pred, w_pred + 3 * (size_t)n); b.meas.assign(meas, meas + 3 * (size_t)n); b.sinv.assign(sinv, sinv + n);
+  P.batches.push_back(std::move(b));
+}
+// ErrorTermTransformation (ABE/src/ErrorTermTransformation.cpp:19-33) on T_a or T_a * inverse(T_b); prior as quaternion
+// [x y z w] + translation per term, like sm::kinematics::Transformation holds it
+inline void describeTransformation(Problem& P, int dv_qa, int dv_ta, int dv_qb, int dv_tb, int n, const double* prior_q,
+                                   const double* prior_t, double weight_rotation, double weight_translation, int mest, double mest_a) {
+  requireOpen(P);
+  P.checkDv(dv_qa, DV_ROTATION_QUATERNION); P.checkDv(dv_ta, DV_EUCLIDEAN_POINT);
+  if ((dv_qb >= 0) != (dv_tb >= 0)) throw std::invalid_argument("the second transformation needs both its rotation and its translation");
+  if (dv_qb >= 0) { P.checkDv(dv_qb, DV_ROTATION_QUATERNION); P.checkDv(dv_tb, DV_EUCLIDEAN_POINT); }
+  checkMest(mest);
+  if (n < 0) throw std::invalid_argument("negative term count");
+  if (!(weight_rotation > 0.0) || !(weight_translation > 0.0)) throw std::invalid_argument("weights must be positive");
+  Batch b;
+  b.kind = KIND_TRANSFORMATION; b.dim = 6; b.n_terms = n; b.mest = mest; b.mest_a = mest_a;
+  b.dv[0] = dv_qa; b.dv[1] = dv_ta; b.dv[2] = dv_qb; b.dv[3] = dv_tb;
+  b.w_t = weight_translation; b.w_r = weight_rotation;
+  b.y.resize(12 * (size_t)n);
+  for (int k = 0; k < n; ++k) {   // inverse(prior): rotation C^T, translation -C^T t
+    Rigid Tp, Ti;
+    quat2r(prior_q + 4 * (size_t)k, Tp.C);
+    Tp.r[0] = prior_t[3 * (size_t)k]; Tp.r[1] = prior_t[3 * (size_t)k + 1]; Tp.r[2] = prior_t[3 * (size_t)k + 2];
+    rigid_inv(Tp, Ti);
+    for (int i = 0; i < 9; ++i) b.y[12 * (size_t)k + i] = Ti.C[i];
+    for (int i = 0; i < 3; ++i) b.y[12 * (size_t)k + 9 + i] = Ti.r[i];
+  }
+  b.sinv.assign(n, 1.0);
+  P.batches.push_back(std::move(b));
+}
+
 inline void describeImu(Problem& P, bool accel, int pose_spline, int bias_spline, int dv_bias, int dv_g, int dv_q_ib, int dv_r_b,
                         int n, const double* t, const double* meas, const double* sinv, int mest, double mest_a) {
   requireOpen(P);

@@ -837,6 +837,78 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// F6 (initialisation problems: GyroscopeError over constants, ErrorTermTransformation).  Every term of a batch writes
+// the same few global blocks (<= 12 columns).  One 256-thread workgroup per group of <= 64 terms: thread = term in the
+// Jacobian phase (rows into an LDS tile laid out by the footprint, last column = residual), thread = Hessian entry in
+// the reduction, one atomic per entry and group.  These problems have a few thousand terms; the shape is chosen for
+// simplicity, not for the last microsecond.
+template <class View> struct SmallTraits;
+template <> struct SmallTraits<GyroPriorBatchView> {
+  enum { D = 3 };
+  static __device__ __forceinline__ bool eval(const GyroPriorBatchView& b, const double* x, int k, bool useM, bool wantJ,
+                                              const int* rolecol, double* J, int ld, double* e, TermOut& out) {
+    return gyro_prior_term(b, x, k, useM, wantJ, rolecol, J, ld, e, out);
+  }
+};
+template <> struct SmallTraits<TransformBatchView> {
+  enum { D = 6 };
+  static __device__ __forceinline__ bool eval(const TransformBatchView& b, const double* x, int k, bool useM, bool wantJ,
+                                              const int* rolecol, double* J, int ld, double* e, TermOut& out) {
+    return transform_term(b, x, k, useM, wantJ, rolecol, J, ld, e, out);
+  }
+};
+enum { SMALL_LD = 13 };   // <= 12 Jacobian columns + residual
+template <class View, bool BUILD>
+__global__ __launch_bounds__(256) void k_small(const View* __restrict__ views, DevCommon dc, const GroupRec* __restrict__ groups,
+                                               int jpart_base) {
+  constexpr int D = SmallTraits<View>::D;
+  __shared__ double tile[BUILD ? GLOBAL_GROUP_TERMS * D * SMALL_LD : 1];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const GroupRec gr = groups[blockIdx.x];
+  const View b = views[gr.batch];
+  FpView f = fp_view(dc, gr.fp);
+  const int C = f.C, R = gr.term_count * D;
+  if (BUILD) {
+    for (int i = tid; i < R * SMALL_LD; i += 256) tile[i] = 0.0;
+    __syncthreads();
+  }
+  double Jacc = 0.0;
+  if (tid < gr.term_count) {
+    const int term = gr.term_first + tid;
+    double e[D];
+    TermOut out;
+    double* Jrow = tile + (size_t)(tid * D) * SMALL_LD;
+    if (SmallTraits<View>::eval(b, dc.x, term, dc.useM != 0, BUILD, f.rolecol, Jrow, SMALL_LD, e, out)) {
+      Jacc = out.w * out.chi2;
+      dc.chi2[b.term_base_global + term] = out.chi2;
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        if (dc.e) dc.e[b.row_base + D * term + r] = -e[r];
+        if (BUILD) Jrow[r * SMALL_LD + C] = e[r];
+      }
+    } else {
+      atomicOr(dc.status, STATUS_INTERNAL);
+    }
+  }
+  Jacc = wave_sum(Jacc);
+  if ((tid & 63) == 0) red[tid >> 6] = Jacc;
+  __syncthreads();
+  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (!BUILD || MC_MODE(dc) == 3) return;
+  const int C1 = C + 1;
+  for (int idx = tid; idx < C1 * C1; idx += 256) {
+    const int cb = idx / C1, ca = idx - cb * C1;
+    if (ca > cb || ca == C) continue;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += tile[r * SMALL_LD + ca] * tile[r * SMALL_LD + cb];
+    if (MC_MODE(dc) != 1) { if (s == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    if (cb == C) atomic_add_f64(dc.rhs + global_col(f, ca), -s);
+    else atomic_add_f64(dc.Cx + entry_addr(f, dc.col_h, ca, cb), s);
+  }
+}
+
 // term evaluation for the J^T kernels: rc[] holds the element index of every role inside the term's CSC column
 __device__ __forceinline__ bool jt_eval(const LidarBatchView& b, const double* x, int u, bool useM, int* rc, const int*, int term_lo,
                                         int nbuf, double* J, int ld, int* st) {
@@ -914,6 +986,18 @@ __global__ __launch_bounds__(64) void k_jt_static(const StaticReprojBatchView* _
     double e[2];
     TermOut out;
     f2_term(b, dc.x, term, dc.useM != 0, true, f.rolecol, jt.values + jt.start[gterm], jt.epc[gterm], e, out);
+  }
+}
+template <class View>
+__global__ __launch_bounds__(64) void k_jt_small(const View* __restrict__ views, DevCommon dc, const GroupRec* __restrict__ groups, JtView jt) {
+  const GroupRec gr = groups[blockIdx.x];
+  const View b = views[gr.batch];
+  FpView f = fp_view(dc, gr.fp);
+  for (int k = threadIdx.x; k < gr.term_count; k += 64) {
+    const int term = gr.term_first + k, gterm = b.term_base_global + term;
+    double e[SmallTraits<View>::D];
+    TermOut out;
+    SmallTraits<View>::eval(b, dc.x, term, dc.useM != 0, true, f.rolecol, jt.values + jt.start[gterm], jt.epc[gterm], e, out);
   }
 }
 template <class View>
@@ -1128,7 +1212,8 @@ struct DevBatch {
 
 // One kernel launch per term family: the batches (sensor streams) of a family share the launch through a device array
 // of their views; work items (groups / chunks) carry the index of their batch.
-enum { LAUNCH_REPROJ = 0, LAUNCH_STATIC = 1, LAUNCH_IMU = 2, LAUNCH_LIDAR = 3, LAUNCH_MOTION = 4, LAUNCH_IMU_SM = 5, N_LAUNCH = 6 };
+enum { LAUNCH_REPROJ = 0, LAUNCH_STATIC = 1, LAUNCH_IMU = 2, LAUNCH_LIDAR = 3, LAUNCH_MOTION = 4, LAUNCH_IMU_SM = 5,
+       LAUNCH_GYRO_PRIOR = 6, LAUNCH_TRANSFORMATION = 7, N_LAUNCH = 8 };
 struct LaunchUnit {
   int n_batches = 0, n_terms = 0, n_items = 0, jpart_base = 0, n_jpart = 0, lds_bytes = 0;
   double flops_dense = 0, flops_live = 0, rec_bytes = 0;
@@ -1142,6 +1227,8 @@ struct LaunchUnit {
   DevBuf<StreamBatch<LidarBatchView>> lviews;
   DevBuf<StreamBatch<ImuSmBatchView>> xviews;
   DevBuf<MotionView> mviews;
+  DevBuf<GyroPriorBatchView> gviews;
+  DevBuf<TransformBatchView> tviews;
   DevBuf<F2Common> common2;  // F2: per observation, rewritten by k_static_common before every k_static
   DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
   DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time; F2: runs of observations of one camera
@@ -1209,6 +1296,8 @@ static int launchOf(int kind) {
     case KIND_ACCEL: case KIND_GYRO: return LAUNCH_IMU;
     case KIND_ACCEL_SM: case KIND_GYRO_SM: return LAUNCH_IMU_SM;
     case KIND_LIDAR: return LAUNCH_LIDAR;
+    case KIND_GYRO_PRIOR: return LAUNCH_GYRO_PRIOR;
+    case KIND_TRANSFORMATION: return LAUNCH_TRANSFORMATION;
     default: return LAUNCH_MOTION;
   }
 }
@@ -1216,8 +1305,8 @@ static int launchOf(int kind) {
 void batchCounts(const Problem& P, const Batch& b, double& fd, double& fl, double& rec) {
   // buildSystem flops with every structurally present block (dense: what the reference computes, padded
   // zero blocks included), with the live blocks only, and the compulsory record bytes
-  static const double fjac[N_KINDS] = {3500.0, 3500.0, 6000.0, 3000.0, 3000.0, 0.0, 9000.0, 9000.0};
-  static const double recb[N_KINDS] = {72.0, 72.0, 52.0, 52.0, 64.0, 0.0, 52.0, 52.0};
+  static const double fjac[N_KINDS] = {3500.0, 3500.0, 6000.0, 3000.0, 3000.0, 0.0, 9000.0, 9000.0, 100.0, 600.0};
+  static const double recb[N_KINDS] = {72.0, 72.0, 52.0, 52.0, 64.0, 0.0, 52.0, 52.0, 56.0, 56.0};
   fd = b.flops_dense; fl = b.flops_live;
   for (const GroupRec& g : b.groups) {
     double s1 = 0, s2 = 0, l1 = 0, l2 = 0;
@@ -1265,6 +1354,8 @@ void mc_context::uploadStructure() {
   std::vector<StreamBatch<LidarBatchView>> lviews;
   std::vector<StreamBatch<ImuSmBatchView>> xviews;
   std::vector<MotionView> mviews;
+  std::vector<GyroPriorBatchView> gviews;
+  std::vector<TransformBatchView> tviews;
   std::vector<ImageRec> images, static_runs;
   // F2: observations per workgroup -- enough workgroups to fill the chip first, then longer runs (fewer camera-level flushes)
   int n_static_obs = 0;
@@ -1381,6 +1472,20 @@ void mc_context::uploadStructure() {
       v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
       sb.order = d->order.p; sb.term_lo = d->term_lo.p; sb.term_nbuf = d->term_nbuf.p;
       iviews.push_back(sb);
+    } else if (b.kind == KIND_GYRO_PRIOR) {
+      d->p.upload(b.p); d->meas.upload(b.meas);
+      GyroPriorBatchView v;
+      v.q = P.dvRef(b.dv[0]); v.bias = P.dvRef(b.dv[1]);
+      v.w_pred = d->p.p; v.meas = d->meas.p; v.sinv = d->sinv.p;
+      v.mest = b.mest; v.mest_a = b.mest_a; v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
+      gviews.push_back(v);
+    } else if (b.kind == KIND_TRANSFORMATION) {
+      d->y.upload(b.y);
+      TransformBatchView v;
+      v.qa = P.dvRef(b.dv[0]); v.ta = P.dvRef(b.dv[1]); v.qb = P.dvRef(b.dv[2]); v.tb = P.dvRef(b.dv[3]);
+      v.prior_inv = d->y.p; v.sw_t = std::sqrt(b.w_t); v.sw_r = std::sqrt(b.w_r);
+      v.mest = b.mest; v.mest_a = b.mest_a; v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
+      tviews.push_back(v);
     } else if (b.kind == KIND_STATIC_REPROJ) {
       d->y.upload(b.y); d->p.upload(b.p);
       d->obs_first.upload(b.obs_first); d->obs_q_off.upload(offs(b.obs_dv_q)); d->obs_t_off.upload(offs(b.obs_dv_t));
@@ -1458,7 +1563,7 @@ void mc_context::uploadStructure() {
         L.images.upload(images);
         L.n_images = (int)images.size();
         L.n_jpart = L.n_images;
-      } else {
+      } else if (l == LAUNCH_STATIC) {
         L.common2.alloc(groups[l].size());
         L.images.upload(static_runs);
         L.n_images = (int)static_runs.size();
@@ -1475,6 +1580,8 @@ void mc_context::uploadStructure() {
   lu[LAUNCH_LIDAR].lviews.upload(lviews);
   lu[LAUNCH_IMU_SM].xviews.upload(xviews);
   lu[LAUNCH_MOTION].mviews.upload(mviews);
+  lu[LAUNCH_GYRO_PRIOR].gviews.upload(gviews);
+  lu[LAUNCH_TRANSFORMATION].tviews.upload(tviews);
   Jpart.alloc(std::max(1, n_jpart));
   Jpart2.alloc(256);
 }
@@ -1495,7 +1602,7 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   }
   if (dE && P.world > 1) HIP_CHECK(hipMemsetAsync(dE, 0, sizeof(double) * P.j_rows, st));
   // per-launch timing (ev) needs the launches back to back on one stream
-  static const int side_of[N_LAUNCH] = {-1, -1, 0, 1, 2, 0};   // reprojection kernels stay on the caller's stream
+  static const int side_of[N_LAUNCH] = {-1, -1, 0, 1, 2, 0, -1, -1};   // reprojection kernels stay on the caller's stream
   const hipStream_t caller = st;
   bool used[N_SIDE] = {false, false, false};
   const bool fork = !ev && sideStreams();
@@ -1532,6 +1639,14 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
       case LAUNCH_IMU_SM:
         if (build) hipLaunchKernelGGL((k_stream<ImuSmBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         else hipLaunchKernelGGL((k_stream<ImuSmBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        break;
+      case LAUNCH_GYRO_PRIOR:
+        if (build) hipLaunchKernelGGL((k_small<GyroPriorBatchView, true>), dim3(L.n_items), dim3(256), 0, st, L.gviews.p, dc, L.groups.p, L.jpart_base);
+        else hipLaunchKernelGGL((k_small<GyroPriorBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.gviews.p, dc, L.groups.p, L.jpart_base);
+        break;
+      case LAUNCH_TRANSFORMATION:
+        if (build) hipLaunchKernelGGL((k_small<TransformBatchView, true>), dim3(L.n_items), dim3(256), 0, st, L.tviews.p, dc, L.groups.p, L.jpart_base);
+        else hipLaunchKernelGGL((k_small<TransformBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.tviews.p, dc, L.groups.p, L.jpart_base);
         break;
       case LAUNCH_MOTION:
         hipLaunchKernelGGL(k_motion, dim3(L.motion_blocks, L.n_items), dim3(256), 0, st, L.mviews.p, dc, L.jpart_base);
@@ -1575,6 +1690,14 @@ void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
   if (lu[LAUNCH_STATIC].n_items) {
     LaunchUnit& L = lu[LAUNCH_STATIC];
     hipLaunchKernelGGL(k_jt_static, dim3(L.n_items), dim3(64), 0, st, L.sviews.p, dc, L.groups.p, jt);
+  }
+  if (lu[LAUNCH_GYRO_PRIOR].n_items) {
+    LaunchUnit& L = lu[LAUNCH_GYRO_PRIOR];
+    hipLaunchKernelGGL(k_jt_small<GyroPriorBatchView>, dim3(L.n_items), dim3(64), 0, st, L.gviews.p, dc, L.groups.p, jt);
+  }
+  if (lu[LAUNCH_TRANSFORMATION].n_items) {
+    LaunchUnit& L = lu[LAUNCH_TRANSFORMATION];
+    hipLaunchKernelGGL(k_jt_small<TransformBatchView>, dim3(L.n_items), dim3(64), 0, st, L.tviews.p, dc, L.groups.p, jt);
   }
   if (lu[LAUNCH_IMU].n_items) {
     LaunchUnit& L = lu[LAUNCH_IMU];
@@ -1638,6 +1761,18 @@ int mc_add_reprojection_batch(mc_context* ctx, int camera, int pose_spline, int 
                               double time_padding, int mest_kind, double mest_param) {
   MC_TRY describeReprojection(ctx->P, camera, pose_spline, dv_q_c_b, dv_t_c_b, dv_time_offset, n_obs, obs_time, obs_dv_q_p_w,
                               obs_dv_t_p_w, obs_first, y, p_target, sqrt_inv_r, time_padding, mest_kind, mest_param);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_add_gyroscope_prior_batch(mc_context* ctx, int dv_q, int dv_bias, int n, const double* w_pred, const double* meas,
+                                 const double* sinv, int mest, double mest_param) {
+  MC_TRY describeGyroPrior(ctx->P, dv_q, dv_bias, n, w_pred, meas, sinv, mest, mest_param); return 0; MC_CATCH(ctx, -1)
+}
+int mc_add_transformation_batch(mc_context* ctx, int dv_q_a, int dv_t_a, int dv_q_b, int dv_t_b, int n, const double* prior_q,
+                                const double* prior_t, double weight_rotation, double weight_translation, int mest,
+                                double mest_param) {
+  MC_TRY describeTransformation(ctx->P, dv_q_a, dv_t_a, dv_q_b, dv_t_b, n, prior_q, prior_t, weight_rotation, weight_translation,
+                                mest, mest_param);
   return 0;
   MC_CATCH(ctx, -1)
 }

@@ -194,6 +194,35 @@ MC_HD void rotvec_dSv_dtheta(const double* th, const double* v, double* D) {
 // ---------------------------------------------------------------- B-spline basis weights
 // Device view of one spline (uniform or not): knots and the per-segment basis matrices that the
 // reference precomputes in BSpline::initializeBasisMatrices (BSP/src/BSpline.cpp:58-121).
+// R2AxisAngle (SM/sm_kinematics/src/rotations.cpp:133-157): axis-angle vector of a rotation matrix, trace clamped into
+// acos' range, zero below 1e-10 (angle or sine).  C row-major.
+MC_HD void r_to_axis_angle(const double* C, double* a) {
+  double tr = (C[0] + C[4] + C[8] - 1.0) * 0.5;
+  tr = tr < -1.0 ? -1.0 : (tr > 1.0 ? 1.0 : tr);
+  const double ang = acos(tr);
+  a[0] = a[1] = a[2] = 0.0;
+  if (fabs(ang) < 1e-10) return;
+  const double ax = C[7] - C[5], ay = C[2] - C[6], az = C[3] - C[1];
+  const double n2 = sqrt(ax * ax + ay * ay + az * az);
+  if (fabs(n2) < 1e-10) return;
+  const double sc = -ang / n2;
+  a[0] = sc * ax; a[1] = sc * ay; a[2] = sc * az;
+}
+// RotationVector::parametersToInverseSMatrix (SM/sm_kinematics/src/RotationVector.cpp:186-201): I + 1/2 p^ + a1 p^ p^
+MC_HD void rotvec_inv_S(const double* p, double* O) {
+  const double phi = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) O[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  if (phi == 0.0) return;
+  const double cot = -sin(phi) / (cos(phi) - 1.0);
+  const double a1 = 1.0 / (phi * phi) * (1.0 - 0.5 * phi * cot);
+  double K[9], KK[9];
+  m3_skew(p, K);
+  m3_mul(K, K, KK);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) O[i] += 0.5 * K[i] + a1 * KK[i];
+}
+
 struct SplineView {
   const double* knots;   // n_knots
   const double* basis;   // n_seg x S x S, row major: basis[seg][k][j] = M_seg(k, j)

@@ -872,6 +872,117 @@ MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, int k,
   }
   return true;
 }
+// ------------------------------------------------------------------------------------------------
+// F6: the error terms of the front-end's initialisation problems (small, a few global design variables each).
+//
+// kalibr GyroscopeError (KAL/src/GyroscopeError.cpp:5-17) as findExtrinsicPriorSensorsToCamera builds it
+// (sensors_and_targets.py:858-879):  e = C(q_i_c) * w_c + b_g - w_meas,  w_c a constant (the camera spline's body rate),
+// design variables q_i_c (RotationQuaternion) and the gyroscope bias (EuclideanPoint).
+enum { GP_ROLE_Q = 0, GP_ROLE_BIAS = 1 };
+struct GyroPriorBatchView {
+  DvRef q, bias;
+  const double* w_pred;   // n x 3: predicted rate in the camera frame (constant)
+  const double* meas;     // n x 3
+  const double* sinv;
+  int mest; double mest_a;
+  int n_terms, row_base, term_base_global;
+};
+MC_HD bool gyro_prior_term(const GyroPriorBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
+                           double* J, int ld, double* e, TermOut& out) {
+  double C[9], p[3];
+  quat2r(x + b.q.off, C);
+  m3_mulv(C, b.w_pred + 3 * (size_t)k, p);
+  const double* bg = x + b.bias.off;
+  const double* m = b.meas + 3 * (size_t)k;
+  double ev[3] = {p[0] + bg[0] - m[0], p[1] + bg[1] - m[1], p[2] + bg[2] - m[2]};
+  const double s = b.sinv[k];
+  out.chi2 = (s * s) * (ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+  out.w = mest_weight(b.mest, b.mest_a, out.chi2);
+  const double sw = (useM ? sqrt(out.w) : 1.0) * s;
+  e[0] = sw * ev[0]; e[1] = sw * ev[1]; e[2] = sw * ev[2];
+  if (!wantJ) return true;
+  // EuclideanExpressionNodeMultiply (ABE/src/EuclideanExpressionNode.cpp:82-86): rotation branch crossMx(C p); bias: I
+  double K[9];
+  m3_skew(p, K);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      if (rolecol[GP_ROLE_Q] >= 0) J[r * ld + rolecol[GP_ROLE_Q] + c] = sw * b.q.scale * K[3 * r + c];
+      if (rolecol[GP_ROLE_BIAS] >= 0) J[r * ld + rolecol[GP_ROLE_BIAS] + c] = (r == c) ? sw * b.bias.scale : 0.0;
+    }
+  return true;
+}
+// ErrorTermTransformation (ABE/src/ErrorTermTransformation.cpp:19-81) over the two expression shapes the front-end
+// builds: T = TransformationDv_a (findExtrinsicPriorSensorsToCamera, sensors_and_targets.py:886-919) or
+// T = TransformationDv_a * inverse(TransformationDv_b) (findTargetPosePrior, :812-817).
+//   E = T * inverse(prior);  e = [ E.t ; R2AxisAngle(E.C) ];  invR = diag(wt wt wt wr wr wr)
+//   chain J6 = [ I  crossMx(E.t) ; 0  invS(axis-angle) ]  into T.evaluateJacobians
+enum { TE_ROLE_QA = 0, TE_ROLE_TA = 1, TE_ROLE_QB = 2, TE_ROLE_TB = 3 };
+struct TransformBatchView {
+  DvRef qa, ta, qb, tb;    // qb.off < 0: no second transformation
+  const double* prior_inv; // n x 12: rotation (row-major 9) and translation of inverse(prior)
+  double sw_t, sw_r;       // sqrt of the translation / rotation weights (sqrtInvR of the diagonal invR)
+  int mest; double mest_a;
+  int n_terms, row_base, term_base_global;
+};
+MC_HD bool transform_term(const TransformBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
+                          double* J, int ld, double* e, TermOut& out) {
+  Rigid Ta, Tb, Tbi, T, Pi, E;
+  load_rigid(x, b.qa.off, b.ta.off, Ta);
+  const bool two = b.qb.off >= 0;
+  if (two) {
+    load_rigid(x, b.qb.off, b.tb.off, Tb);
+    rigid_inv(Tb, Tbi);
+    rigid_mul(Ta, Tbi, T);
+  } else {
+    T = Ta; Tb = Ta; Tbi = Ta;
+  }
+  const double* pi = b.prior_inv + 12 * (size_t)k;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Pi.C[i] = pi[i];
+  Pi.r[0] = pi[9]; Pi.r[1] = pi[10]; Pi.r[2] = pi[11];
+  rigid_mul(T, Pi, E);
+  double aa[3];
+  r_to_axis_angle(E.C, aa);
+  const double ev[6] = {E.r[0], E.r[1], E.r[2], aa[0], aa[1], aa[2]};
+  double chi2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { const double s = r < 3 ? b.sw_t : b.sw_r; chi2 += (s * ev[r]) * (s * ev[r]); }
+  out.chi2 = chi2;
+  out.w = mest_weight(b.mest, b.mest_a, chi2);
+  const double sm = useM ? sqrt(out.w) : 1.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) e[r] = sm * (r < 3 ? b.sw_t : b.sw_r) * ev[r];
+  if (!wantJ) return true;
+  double Kt[9], iS[9];
+  m3_skew(E.r, Kt);
+  rotvec_inv_S(aa, iS);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    // row r of J6, weighted: [u | v]
+    const double f = sm * (r < 3 ? b.sw_t : b.sw_r);
+    double u[3] = {0.0, 0.0, 0.0}, v[3];
+    if (r < 3) { u[r] = f; v[0] = f * Kt[3 * r]; v[1] = f * Kt[3 * r + 1]; v[2] = f * Kt[3 * r + 2]; }
+    else { v[0] = f * iS[3 * (r - 3)]; v[1] = f * iS[3 * (r - 3) + 1]; v[2] = f * iS[3 * (r - 3) + 2]; }
+    double* row = J + r * ld;
+    double Jq[3], Jt[3];
+    // lhs of Multiply (or the single leaf): TransformationBasic(q_a, t_a)
+    chain_basic(u, v, Ta.r, Jq, Jt);
+    if (rolecol[TE_ROLE_QA] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[TE_ROLE_QA] + c] = Jq[c] * b.qa.scale;
+    if (rolecol[TE_ROLE_TA] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[TE_ROLE_TA] + c] = Jt[c] * b.ta.scale;
+    if (two) {
+      // rhs: chain * boxTimes(T_a), through the inverse node * (-boxTimes(inverse(T_b)))
+      double u2[3], v2[3], u3[3], v3[3];
+      chain_boxtimes(u, v, Ta, u2, v2);
+      chain_boxtimes(u2, v2, Tbi, u3, v3);
+      u3[0] = -u3[0]; u3[1] = -u3[1]; u3[2] = -u3[2]; v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2];
+      chain_basic(u3, v3, Tb.r, Jq, Jt);
+      if (rolecol[TE_ROLE_QB] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[TE_ROLE_QB] + c] = Jq[c] * b.qb.scale;
+      if (rolecol[TE_ROLE_TB] >= 0) for (int c = 0; c < 3; ++c) row[rolecol[TE_ROLE_TB] + c] = Jt[c] * b.tb.scale;
+    }
+  }
+  return true;
+}
+
 MC_HD bool f2_term(const StaticReprojBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
                    double* J, int ld, double* e, TermOut& out, int rmask = 3) {
   F2Common cm;

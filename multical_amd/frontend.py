@@ -536,6 +536,26 @@ class EuclideanError(ErrorTerm):
         self.invR, self.predicted = np.asarray(invR, dtype=np.float64), predicted
 
 
+class GyroscopeError(EuclideanError):
+    """kalibr_errorterms GyroscopeError(measurement, invR, angularVelocity, bias): a EuclideanError on
+    angularVelocity + bias (kalibr/src/GyroscopeError.cpp:5-17)."""
+
+    def __init__(self, measurement, invR, angularVelocity, bias):
+        EuclideanError.__init__(self, measurement, invR, angularVelocity + bias)
+
+
+class ErrorTermTransformation(ErrorTerm):
+    """aopt.ErrorTermTransformation(T, prior, weightRotation, weightTranslation)
+    (aslam_backend_expressions/src/ErrorTermTransformation.cpp:19-33)."""
+
+    def __init__(self, T, prior, weightRotation, weightTranslation):
+        ErrorTerm.__init__(self)
+        if not isinstance(prior, Transformation):
+            raise RuntimeError("The prior must be an sm transformation")
+        self.T, self.prior = T, prior
+        self.weightRotation, self.weightTranslation = float(weightRotation), float(weightTranslation)
+
+
 class ScalarError(ErrorTerm):
     """kalibr_errorterms ScalarError(measurement, invR, predicted)."""
 
@@ -691,6 +711,32 @@ def _match_gyro(term):
         return None
     return dict(spline=w[0], t=w[1], q_ib=rm[1].node[1], bias_spline=bias[0], bias_dv=bias[1], meas=term.meas,
                 sinv=_isotropic(term.invR, "gyroscope error"))
+
+
+def _match_gyro_prior(term):
+    """R_i_c * const + bias   (findExtrinsicPriorSensorsToCamera, sensors_and_targets.py:871-879)"""
+    n = term.predicted.node
+    if n[0] != "e_add":
+        return None
+    rm, b = n[1].node, n[2].node
+    if rm[0] != "e_rot_mul" or rm[1].node[0] != "r_leaf" or rm[2].node[0] != "e_const":
+        return None
+    if b[0] != "e_leaf" or b[1].kind != S.DV_EUCLIDEAN_POINT:
+        return None
+    return dict(q=rm[1].node[1], bias=b[1], w_pred=rm[2].node[1], meas=term.meas, sinv=_isotropic(term.invR, "gyroscope error"))
+
+
+def _match_transformation(term):
+    """T_a or T_a * T_b.inverse() over TransformationDv leaves (sensors_and_targets.py:812-817, 886-919)"""
+    a = _match_t_leaf(term.T)
+    if a is not None:
+        return dict(a=a, b=(None, None))
+    n = term.T.node
+    if n[0] == "t_mul" and n[2].node[0] == "t_inv":
+        a, b = _match_t_leaf(n[1]), _match_t_leaf(n[2].node[1])
+        if a is not None and b is not None:
+            return dict(a=a, b=b)
+    return None
 
 
 def _match_gravity_part(e):
@@ -903,6 +949,12 @@ def lower(problem):
             sp.add_accelerometer_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["g"], run["q_ib"], run["r_b"],
                                           run["M"], run["size_effect"], np.array(run["t"]), np.array(run["meas"]),
                                           np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
+        elif kind == "gyro_prior":
+            sp.add_gyroscope_prior_batch(run["q"], run["bias"], np.array(run["w_pred"]), np.array(run["meas"]), np.array(run["sinv"]),
+                                         run["mest"].kind, run["mest"].param)
+        elif kind == "transformation":
+            sp.add_transformation_batch(run["qa"], run["ta"], run["qb"], run["tb"], np.array(run["prior_q"]), np.array(run["prior_t"]),
+                                        run["wr"], run["wt"], run["mest"].kind, run["mest"].param)
         elif kind == "gyro_sm":
             sp.add_gyroscope_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], run["q_gi"], run["M"],
                                       run["Ma"], run["g"], run["r_b"], np.array(run["t"]), np.array(run["meas"]),
@@ -947,6 +999,20 @@ def lower(problem):
                   mest=term.mest, t=[], dir=[], range=[], sinv=[], q_pw=[], t_pw=[])
             run["t"].append(m["time"]); run["dir"].append(m["dir"]); run["range"].append(m["range"]); run["sinv"].append(m["sinv"])
             run["q_pw"].append(h(m["q_pw"])); run["t_pw"].append(h(m["t_pw"]))
+        elif isinstance(term, ErrorTermTransformation):
+            m = _match_transformation(term)
+            if m is None:
+                raise UnsupportedErrorTerm("transformation error over an expression that is not T_a or T_a * T_b^-1 of TransformationDvs")
+            key = ("transformation", id(m["a"][0]), id(m["a"][1]), id(m["b"][0]), id(m["b"][1]), term.weightRotation,
+                   term.weightTranslation, mk)
+            start(key, qa=h(m["a"][0]), ta=h(m["a"][1]), qb=h(m["b"][0]), tb=h(m["b"][1]), wr=term.weightRotation,
+                  wt=term.weightTranslation, mest=term.mest, prior_q=[], prior_t=[])
+            run["prior_q"].append(term.prior.q()); run["prior_t"].append(term.prior.t())
+        elif isinstance(term, EuclideanError) and _match_gyro_prior(term) is not None:
+            m = _match_gyro_prior(term)
+            key = ("gyro_prior", id(m["q"]), id(m["bias"]), mk)
+            start(key, q=h(m["q"]), bias=h(m["bias"]), mest=term.mest, w_pred=[], meas=[], sinv=[])
+            run["w_pred"].append(m["w_pred"]); run["meas"].append(m["meas"]); run["sinv"].append(m["sinv"])
         elif isinstance(term, EuclideanError):
             m = None
             for kind, matcher in (("accel", _match_accel), ("gyro", _match_gyro), ("accel_sm", _match_accel_sm),

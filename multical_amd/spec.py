@@ -115,6 +115,23 @@ class ProblemSpec(object):
                                        mest_param=float(mest_param))))
         return len(self.ops) - 1
 
+    def add_gyroscope_prior_batch(self, dv_q, dv_bias, w_pred, meas, sinv, mest=MEST_NONE, mest_param=0.0):
+        """ket.GyroscopeError(omega_measured, invR, R_i_c * const, bias) (sensors_and_targets.py:858-879)"""
+        self.ops.append(("gyro_prior", dict(dv_q=dv_q, dv_bias=dv_bias, w_pred=_f64(w_pred).reshape(-1, 3),
+                                            meas=_f64(meas).reshape(-1, 3), sinv=_f64(sinv), mest=mest, mest_param=float(mest_param))))
+        return len(self.ops) - 1
+
+    def add_transformation_batch(self, dv_q_a, dv_t_a, dv_q_b, dv_t_b, prior_q, prior_t, weight_rotation=1.0, weight_translation=0.1,
+                                 mest=MEST_NONE, mest_param=0.0):
+        """aopt.ErrorTermTransformation(T_a [* T_b.inverse()], prior, weightRotation, weightTranslation)
+        (sensors_and_targets.py:812-817, 886-919); dv_q_b = dv_t_b = None for the single-transformation form"""
+        prior_q, prior_t = _f64(prior_q).reshape(-1, 4), _f64(prior_t).reshape(-1, 3)
+        self.ops.append(("transformation", dict(dv_q_a=dv_q_a, dv_t_a=dv_t_a, dv_q_b=dv_q_b, dv_t_b=dv_t_b, prior_q=prior_q,
+                                                prior_t=prior_t, weight_rotation=float(weight_rotation),
+                                                weight_translation=float(weight_translation), sinv=np.ones(prior_t.shape[0]),
+                                                mest=mest, mest_param=float(mest_param))))
+        return len(self.ops) - 1
+
     def add_motion_term(self, spline, W, order):
         self.ops.append(("motion", dict(spline=spline, W=_f64(W), order=int(order))))
         return len(self.ops) - 1
@@ -191,6 +208,13 @@ class ProblemSpec(object):
                 api.add_lidar_batch(sid(d["spline"]), dvid(d["dv_toff"]), dvid(d["dv_q_lb"]), dvid(d["dv_t_lb"]), d["t"],
                                     d["dir"], d["range"], d["sinv"], _i32([dvid(h) for h in d["dv_q_pw"]]),
                                     _i32([dvid(h) for h in d["dv_t_pw"]]), d["pad"], d["mest"], d["mest_param"])
+            elif k == "gyro_prior":
+                api.add_gyroscope_prior_batch(dvid(d["dv_q"]), dvid(d["dv_bias"]), d["w_pred"], d["meas"], d["sinv"], d["mest"],
+                                              d["mest_param"])
+            elif k == "transformation":
+                api.add_transformation_batch(dvid(d["dv_q_a"]), dvid(d["dv_t_a"]), dvid(d["dv_q_b"]), dvid(d["dv_t_b"]),
+                                             d["prior_q"], d["prior_t"], d["weight_rotation"], d["weight_translation"], d["mest"],
+                                             d["mest_param"])
             elif k == "motion":
                 api.add_motion_term(sid(d["spline"]), d["W"], d["order"])
         return ids

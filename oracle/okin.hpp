@@ -112,7 +112,31 @@ inline Mat yprToRotationMatrix(double yaw, double pitch, double roll) {
   return C;
 }
 
+// SM/sm_kinematics/src/rotations.cpp:133-157  R2AxisAngle
+inline Mat R2AxisAngle(const Mat& C) {
+  double tr = std::max(-1.0, std::min((C(0, 0) + C(1, 1) + C(2, 2) - 1.0) * 0.5, 1.0));
+  double a = std::acos(tr);
+  Mat axis(3, 1);
+  if (std::fabs(a) < 1e-10) return axis;
+  axis[0] = C(2, 1) - C(1, 2);
+  axis[1] = C(0, 2) - C(2, 0);
+  axis[2] = C(1, 0) - C(0, 1);
+  double n2 = axis.norm();
+  if (std::fabs(n2) < 1e-10) return Mat(3, 1);
+  return axis * (-a / n2);
+}
+
 // ---- RotationVector: SM/sm_kinematics/src/RotationVector.cpp ----
+
+// :186-201 parametersToInverseSMatrix
+inline Mat rvInverseSMatrix(const Mat& p) {
+  double phi = std::sqrt(p.dot(p));
+  if (phi == 0) return Mat::Identity(3);
+  double cot = -std::sin(phi) / (std::cos(phi) - 1);
+  double a1 = 1 / (phi * phi) * (1 - 0.5 * phi * cot);
+  Mat K = crossMx(p);
+  return Mat::Identity(3) + (0.5 * K) + (a1 * (K * K));
+}
 
 // :82-106 parametersToSMatrix
 inline Mat rvSMatrix(const Mat& p) {

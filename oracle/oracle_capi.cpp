@@ -234,6 +234,51 @@ int orc_add_gyro_batch(void* h, int poseSpline, int biasSpline, int dvBias, int 
   ORC_CATCH(P, -1)
 }
 
+// F6: ket.GyroscopeError(omega_measured, invR, R_i_c * EuclideanExpression(const), bias) in
+// findExtrinsicPriorSensorsToCamera (sensors_and_targets.py:858-879); GyroscopeError = EuclideanError on
+// angularVelocity + bias (KAL/src/GyroscopeError.cpp:5-17)
+int orc_add_gyroscope_error_batch(void* h, int dvQ, int dvBias, int n, const double* wPred, const double* meas, const double* sinv,
+                                  int mestKind, double mestParam) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  RotP R_i_c(new RotationQuaternionNode(P->dvAs<RotationQuaternion>(dvQ)));
+  EucP bias(new EuclideanPointNode(P->dvAs<EuclideanPoint>(dvBias)));
+  for (int k = 0; k < n; ++k) {
+    EucP wc(new EuclideanConstantNode(Mat::Vec({wPred[3 * k], wPred[3 * k + 1], wPred[3 * k + 2]})));
+    EucP w(new EuclideanRotateNode(R_i_c, wc));
+    EucP pred(new EuclideanAddNode(w, bias));
+    std::unique_ptr<EuclideanError> e(new EuclideanError(&meas[3 * k], sinv[k], pred));
+    e->mest.kind = mestKind; e->mest.a = mestParam;
+    P->terms.push_back(std::move(e));
+  }
+  return 0;
+  ORC_CATCH(P, -1)
+}
+// F6: aopt.ErrorTermTransformation(T_a [* T_b.inverse()], prior, weightRotation, weightTranslation)
+// (sensors_and_targets.py:812-817, 886-919); the prior's inverse as sm::kinematics::Transformation::inverse() forms it
+// (conjugate quaternion, rotated and negated translation)
+int orc_add_transformation_error_batch(void* h, int dvQa, int dvTa, int dvQb, int dvTb, int n, const double* priorQ,
+                                       const double* priorT, double weightRotation, double weightTranslation, int mestKind,
+                                       double mestParam) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  TraP T = P->basicT(dvQa, dvTa);
+  if (dvQb >= 0) T = TraP(new TransformationMultiplyNode(T, TraP(new TransformationInverseNode(P->basicT(dvQb, dvTb)))));
+  for (int k = 0; k < n; ++k) {
+    Mat qi = Mat::Vec({-priorQ[4 * k], -priorQ[4 * k + 1], -priorQ[4 * k + 2], priorQ[4 * k + 3]});
+    Mat Ci = quat2r(qi);
+    Mat t = Mat::Vec({priorT[3 * k], priorT[3 * k + 1], priorT[3 * k + 2]});
+    Mat Pi = Mat::Identity(4);
+    Pi.setBlock(0, 0, Ci);
+    Pi.setBlock(0, 3, (Ci * t) * -1.0);
+    std::unique_ptr<ErrorTermTransformation> e(new ErrorTermTransformation(T, Pi, weightRotation, weightTranslation));
+    e->mest.kind = mestKind; e->mest.a = mestParam;
+    P->terms.push_back(std::move(e));
+  }
+  return 0;
+  ORC_CATCH(P, -1)
+}
+
 static EucP gravityExpr(Problem* P, int dvGravity) {
   if (P->dvKind[dvGravity] == DV_EUCLIDEAN_DIRECTION) return EucP(new EuclideanDirectionNode(P->dvAs<EuclideanDirection>(dvGravity)));
   return EucP(new EuclideanPointNode(P->dvAs<EuclideanPoint>(dvGravity)));

@@ -207,6 +207,30 @@ struct EuclideanError : ErrorTerm {
   void evaluateJacobiansImplementation(JacobianContainer& jc) override { pred->evalJ(jc, nullptr); }
   void getDvs(std::set<DesignVariable*>& s) override { pred->getDvs(s); }
 };
+// --- ABE/src/ErrorTermTransformation.cpp:19-81 (the weightRotation / weightTranslation constructor)
+struct ErrorTermTransformation : ErrorTerm {
+  TraP T;
+  Mat priorInv;     // inverse(prior).T()
+  Mat errorMatrix;
+  ErrorTermTransformation(TraP T_, const Mat& priorInv_, double weightRotation, double weightTranslation)
+      : ErrorTerm(6), T(T_), priorInv(priorInv_) {
+    // invR = diag(wt wt wt wr wr wr); its LDL^T square root is the diagonal of square roots
+    for (int i = 0; i < 6; ++i) sqrtInvR(i, i) = std::sqrt(i < 3 ? weightTranslation : weightRotation);
+  }
+  double evaluateErrorImplementation() override {
+    errorMatrix = T->toT() * priorInv;
+    error.setBlock(0, 0, errorMatrix.block(0, 3, 3, 1));
+    error.setBlock(3, 0, R2AxisAngle(errorMatrix.block(0, 0, 3, 3)));
+    return evaluateChiSquaredError();
+  }
+  void evaluateJacobiansImplementation(JacobianContainer& jc) override {
+    Mat J = Mat::Identity(6);
+    J.setBlock(0, 3, crossMx(errorMatrix.block(0, 3, 3, 1)));
+    J.setBlock(3, 3, rvInverseSMatrix(R2AxisAngle(errorMatrix.block(0, 0, 3, 3))));
+    T->evalJ(jc, &J);
+  }
+  void getDvs(std::set<DesignVariable*>& s) override { T->getDvs(s); }
+};
 // --- KAL/src/ScalarError.cpp:6-31
 struct ScalarError : ErrorTerm {
   double meas;

@@ -46,6 +46,13 @@ int probe_add_static_reprojection_batch(void* h, int cam, int nc, const int* cq,
                                         const int* of, const double* y, const double* p, const double* s, int m, double ma) {
   Probe* pr = (Probe*)h; PR_TRY describeStaticReprojection(pr->P, cam, nc, cq, ct, n_obs, oq, ot, of, y, p, s, m, ma); return 0; PR_CATCH(pr, -1)
 }
+int probe_add_gyroscope_prior_batch(void* h, int dq, int db, int n, const double* wp, const double* me, const double* s, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeGyroPrior(pr->P, dq, db, n, wp, me, s, m, ma); return 0; PR_CATCH(pr, -1)
+}
+int probe_add_transformation_batch(void* h, int qa, int ta, int qb, int tb, int n, const double* pq, const double* pt, double wr,
+                                   double wt, int m, double ma) {
+  Probe* pr = (Probe*)h; PR_TRY describeTransformation(pr->P, qa, ta, qb, tb, n, pq, pt, wr, wt, m, ma); return 0; PR_CATCH(pr, -1)
+}
 int probe_add_accelerometer_batch(void* h, int ps, int bs, int db, int dg, int dq, int dr, int n, const double* t, const double* me,
                                   const double* s, int m, double ma) {
   Probe* pr = (Probe*)h; PR_TRY describeImu(pr->P, true, ps, bs, db, dg, dq, dr, n, t, me, s, m, ma); return 0; PR_CATCH(pr, -1)
@@ -223,6 +230,18 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     for (int j = 0; j < v.n_chain; ++j) { rolecol[F2_ROLE_CHAIN + 2 * j] = v.chain_q[j].col; rolecol[F2_ROLE_CHAIN + 2 * j + 1] = v.chain_t[j].col; }
     rolecol[F2_ROLE_PROJ] = v.cam.proj_col; rolecol[F2_ROLE_DIST] = v.cam.dist_col;
     f2_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out);
+  } else if (B.kind == KIND_GYRO_PRIOR) {
+    GyroPriorBatchView v;
+    v.q = P.dvRef(B.dv[0]); v.bias = P.dvRef(B.dv[1]);
+    v.w_pred = B.p.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    rolecol[GP_ROLE_Q] = v.q.col; rolecol[GP_ROLE_BIAS] = v.bias.col;
+    gyro_prior_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out);
+  } else if (B.kind == KIND_TRANSFORMATION) {
+    TransformBatchView v;
+    v.qa = P.dvRef(B.dv[0]); v.ta = P.dvRef(B.dv[1]); v.qb = P.dvRef(B.dv[2]); v.tb = P.dvRef(B.dv[3]);
+    v.prior_inv = B.y.data(); v.sw_t = std::sqrt(B.w_t); v.sw_r = std::sqrt(B.w_r); v.mest = B.mest; v.mest_a = B.mest_a;
+    rolecol[TE_ROLE_QA] = v.qa.col; rolecol[TE_ROLE_TA] = v.ta.col; rolecol[TE_ROLE_QB] = v.qb.col; rolecol[TE_ROLE_TB] = v.tb.col;
+    transform_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out);
   } else {
     throw std::runtime_error("probe_term: motion terms have no Jacobian");
   }

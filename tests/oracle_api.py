@@ -120,6 +120,19 @@ class OracleApi(object):
                                               C.c_int(dv_q_ib), C.c_int(t.size), _d(t), _d(meas), _d(sinv), C.c_int(mest),
                                               C.c_double(mest_param)))
 
+    def add_gyroscope_prior_batch(self, dv_q, dv_bias, w_pred, meas, sinv, mest=0, mest_param=0.0):
+        w_pred, meas, sinv = _f64(w_pred), _f64(meas), _f64(sinv)
+        self._chk(self.lib.orc_add_gyroscope_error_batch(self.h, C.c_int(dv_q), C.c_int(dv_bias), C.c_int(sinv.size), _d(w_pred),
+                                                         _d(meas), _d(sinv), C.c_int(mest), C.c_double(mest_param)))
+
+    def add_transformation_batch(self, dv_q_a, dv_t_a, dv_q_b, dv_t_b, prior_q, prior_t, weight_rotation, weight_translation,
+                                 mest=0, mest_param=0.0):
+        prior_q, prior_t = _f64(prior_q), _f64(prior_t)
+        self._chk(self.lib.orc_add_transformation_error_batch(self.h, C.c_int(dv_q_a), C.c_int(dv_t_a), C.c_int(dv_q_b), C.c_int(dv_t_b),
+                                                              C.c_int(prior_t.size // 3), _d(prior_q), _d(prior_t),
+                                                              C.c_double(weight_rotation), C.c_double(weight_translation),
+                                                              C.c_int(mest), C.c_double(mest_param)))
+
     def add_matrix_design_variable(self, A, pattern, active=True, scaling=1.0):
         A, pattern = _f64(A).reshape(9), _i32(pattern).reshape(9)
         return self._chk(self.lib.orc_add_matrix_dv(self.h, _d(A), _i(pattern), C.c_int(int(bool(active))), C.c_double(scaling)))

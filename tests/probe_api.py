@@ -70,6 +70,17 @@ class ProbeApi(object):
         self._chk(self.L.probe_add_static_reprojection_batch(self.h, C.c_int(cam), C.c_int(cq.size), _i(cq), _i(ct), C.c_int(oq.size),
                                                              _i(oq), _i(ot), _i(of), _d(y), _d(p), _d(s), C.c_int(m), C.c_double(ma)))
 
+    def add_gyroscope_prior_batch(self, dq, db, wp, me, s, m=0, ma=0.0):
+        wp, me, s = _f64(wp), _f64(me), _f64(s)
+        self._chk(self.L.probe_add_gyroscope_prior_batch(self.h, C.c_int(dq), C.c_int(db), C.c_int(s.size), _d(wp), _d(me), _d(s),
+                                                         C.c_int(m), C.c_double(ma)))
+
+    def add_transformation_batch(self, qa, ta, qb, tb, pq, pt, wr, wt, m=0, ma=0.0):
+        pq, pt = _f64(pq), _f64(pt)
+        self._chk(self.L.probe_add_transformation_batch(self.h, C.c_int(qa), C.c_int(ta), C.c_int(qb), C.c_int(tb),
+                                                        C.c_int(pt.size // 3), _d(pq), _d(pt), C.c_double(wr), C.c_double(wt),
+                                                        C.c_int(m), C.c_double(ma)))
+
     def add_accelerometer_batch(self, ps, bs, db, dg, dq, dr, t, me, s, m=0, ma=0.0):
         t, me, s = _f64(t), _f64(me), _f64(s)
         self._chk(self.L.probe_add_accelerometer_batch(self.h, C.c_int(ps), C.c_int(bs), C.c_int(db), C.c_int(dg), C.c_int(dq),
@@ -125,8 +136,8 @@ class ProbeApi(object):
         return Cp, Ci
 
     def term(self, t, use_mest=True):
-        J = np.zeros((3, self.j_cols))
-        e = np.zeros(3)
+        J = np.zeros((6, self.j_cols))
+        e = np.zeros(6)
         c = C.c_double()
         d = self._chk(self.L.probe_term(self.h, C.c_int(t), C.c_int(int(use_mest)), _d(J), _d(e), C.byref(c)))
         return J[:d], e[:d], c.value

@@ -1,0 +1,263 @@
+"""F6: the error terms of the front-end's initialisation problems -- kalibr GyroscopeError over constants
+(kalibr/src/GyroscopeError.cpp:5-17) and aslam::backend::ErrorTermTransformation
+(aslam_backend_expressions/src/ErrorTermTransformation.cpp:19-81) -- as findTargetPosePrior and
+findExtrinsicPriorSensorsToCamera compose them (kalibr_sensor_calibration/sensors_and_targets.py:760-935).
+
+CPU: the oracle against the identities the reference's own tests assert for these terms (finite differences at the
+ErrorTermTestHarness tolerance, KAL/test/TestErrorTerms.cpp:36-49 and ASP/test/TestOPTBSpline.cpp:429; H = J^T J,
+rhs = -J^T e) and the product's closed forms (tests/hostprobe) against the oracle.  GPU: the HIP path through the C ABI
+against the oracle at 1e-9, both solver backends, and the Levenberg-Marquardt run to the same estimates (1e-7)."""
+import numpy as np
+import pytest
+
+from test_oracle_identities import _fd_check
+
+RTOL = 1e-9
+
+
+def _problems():
+    from multical_amd import spec as S
+    from multical_amd import synth_init as SI
+    return {
+        "target_pose_prior": SI.make_target_pose_prior(n_targets=3, n_meas=12)[0],
+        "target_pose_prior_cauchy": SI.make_target_pose_prior(n_targets=4, n_meas=5, seed=3, mest=S.MEST_CAUCHY, mest_param=2.0)[0],
+        "extrinsic_prior": SI.make_extrinsic_prior(n_gyro=300, n_other=2, n_obs=25)[0],
+        "extrinsic_prior_huber": SI.make_extrinsic_prior(n_gyro=150, n_other=1, n_obs=70, seed=5, huber_gyro=1.0,
+                                                         mest_transform=(S.MEST_HUBER, 0.5))[0],
+        "gyro_only": SI.make_extrinsic_prior(n_gyro=90, n_other=0)[0],
+    }
+
+
+@pytest.fixture(scope="module")
+def problems():
+    from oracle_api import OracleApi
+    out = {}
+    for name, sp in _problems().items():
+        o = OracleApi()
+        ids = sp.emit(o)
+        o.finalize()
+        out[name] = dict(spec=sp, oracle=o, ids=ids)
+    return out
+
+
+NAMES = ["target_pose_prior", "target_pose_prior_cauchy", "extrinsic_prior", "extrinsic_prior_huber", "gyro_only"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_jacobians_match_finite_differences(problems, name):
+    o = problems[name]["oracle"]
+    _fd_check(o, list(range(0, o.n_terms, max(1, o.n_terms // 25))), 1e-6)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_system_is_dense_normal_equations(problems, name):
+    o = problems[name]["oracle"]
+    o.evaluate_error(True)
+    Cp, Ci, Cx, rhs = o.build_system(True)
+    n = o.j_cols
+    Hd, g = np.zeros((n, n)), np.zeros(n)
+    for t in range(o.n_terms):
+        J, e = o.term_weighted_jacobian(t, True)
+        Hd += J.T @ J
+        g -= J.T @ e
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    assert np.abs(Hd[Ci, cols] - Cx).max() <= 1e-12 * np.abs(Cx).max()
+    assert np.abs(g - rhs).max() <= 1e-12 * np.abs(rhs).max()
+    mask = np.zeros((n, n), bool)
+    mask[Ci, cols] = True
+    assert not np.any(np.triu(Hd != 0.0) & ~mask)
+
+
+def test_transformation_error_is_zero_at_the_prior():
+    """ErrorTermTransformation of T against T itself: zero error (TestOPTBSpline.cpp builds the term the same way)."""
+    from multical_amd import spec as S
+    from multical_amd.synth import quat_from_matrix, rotvec_to_matrix
+    from oracle_api import OracleApi
+    C, t = rotvec_to_matrix(np.array([0.3, -0.2, 0.5])), np.array([0.4, -1.0, 2.0])
+    sp = S.ProblemSpec()
+    q = sp.add_dv(S.DV_ROTATION_QUATERNION, quat_from_matrix(C))
+    tv = sp.add_dv(S.DV_EUCLIDEAN_POINT, t)
+    sp.add_transformation_batch(q, tv, None, None, quat_from_matrix(C)[None], t[None], 1.0, 0.1)
+    o = OracleApi()
+    sp.emit(o)
+    o.finalize()
+    J, e = o.evaluate_error(False)
+    assert np.abs(e).max() < 1e-12 and J < 1e-24
+
+
+@pytest.mark.parametrize("use_mest", [True, False])
+@pytest.mark.parametrize("name", NAMES)
+def test_product_math_matches_oracle(problems, name, use_mest):
+    from probe_api import ProbeApi
+    o = problems[name]["oracle"]
+    p = ProbeApi()
+    problems[name]["spec"].emit(p)
+    p.finalize()
+    o.evaluate_error(use_mest)
+    Cp, Ci, _, _ = o.build_system(use_mest)
+    Cp2, Ci2 = p.pattern()
+    assert np.array_equal(Cp, Cp2) and np.array_equal(Ci, Ci2)
+    chi = o.term_chi2()
+    wj = we = wc = 0.0
+    for t in range(o.n_terms):
+        Ja, ea = o.term_weighted_jacobian(t, use_mest)
+        Jp, ep, c = p.term(t, use_mest)
+        wj = max(wj, np.abs(Ja - Jp).max() / np.abs(Ja).max())
+        we = max(we, np.abs(ea - ep).max() / max(1e-9, np.abs(ea).max()))
+        wc = max(wc, abs(c - chi[t]) / max(1e-9, chi[t]))
+    assert wj < RTOL and we < RTOL and wc < RTOL, (wj, we, wc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_mest", [True, False])
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_parity(problems, name, use_mest):
+    from multical_amd.backend import HipApi
+    o = problems[name]["oracle"]
+    g = HipApi(0)
+    problems[name]["spec"].emit(g)
+    g.finalize()
+    Jo, eo = o.evaluate_error(use_mest)
+    Cp, Ci, Cx, rhs = o.build_system(use_mest)
+    Cpg, Cig = g.pattern()
+    assert np.array_equal(Cp, Cpg) and np.array_equal(Ci, Cig)
+    Jg, eg = g.evaluate_error(use_mest)
+    assert abs(Jg - Jo) <= RTOL * abs(Jo)
+    assert np.abs(eg - eo).max() <= RTOL * np.abs(eo).max()
+    Cxg, rhsg = g.build_system(use_mest)
+    assert np.abs(Cxg - Cx).max() <= RTOL * np.abs(Cx).max()
+    assert np.linalg.norm(Cxg - Cx) <= RTOL * np.linalg.norm(Cx)
+    assert np.abs(rhsg - rhs).max() <= RTOL * np.abs(rhs).max()
+    g.check_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["target_pose_prior", "extrinsic_prior_huber"])
+def test_gpu_jacobian_transpose(problems, name):
+    """Second backend on the same problems (these run with BlockCholesky in the reference, but the J^T builder must lay
+    out any error term the first backend accepts)."""
+    from multical_amd.backend import HipApi
+    o = problems[name]["oracle"]
+    g = HipApi(0)
+    problems[name]["spec"].emit(g)
+    g.finalize()
+    o.evaluate_error(True)
+    g.evaluate_error(True)
+    cp, ri, v = o.jacobian_transpose(True)
+    cpg, rig = g.jt_pattern()
+    assert np.array_equal(cp, cpg) and np.array_equal(ri, rig)
+    vg = g.build_jacobian_transpose(True)
+    assert np.abs(vg - v).max() <= RTOL * np.abs(v).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["target_pose_prior", "extrinsic_prior"])
+def test_gpu_levenberg_marquardt_matches_oracle(name):
+    """The initialisation problems are solved with Optimizer2 + BlockCholesky (sensors_and_targets.py:819-838, 925-935):
+    same accepted / rejected sequence as the oracle's restatement of that loop, estimates within 1e-7, and the estimate is
+    the prior the front-end expects (truth within the measurement noise)."""
+    from multical_amd import synth_init as SI
+    from multical_amd.backend import (HipApi, HipBlockCholeskyLinearSystemSolver, LevenbergMarquardtTrustRegionPolicy, Optimizer2,
+                                      Optimizer2Options)
+    from multical_amd.synth import quat_from_matrix
+    from oracle_api import OracleApi
+    sp, H = SI.make_target_pose_prior() if name == "target_pose_prior" else SI.make_extrinsic_prior()
+    o = OracleApi()
+    oids = sp.emit(o)
+    o.finalize()
+    g = HipApi(0)
+    gids = sp.emit(g)
+    g.finalize()
+    iters = 8
+    opt = Optimizer2Options()
+    opt.maxIterations, opt.convergenceDeltaX, opt.convergenceJDescentRatioThreshold = iters, 1e-4, 1e-5
+    opt.linearSolver = HipBlockCholeskyLinearSystemSolver(g)
+    opt.trustRegionPolicy = LevenbergMarquardtTrustRegionPolicy(10.0)
+    rv = Optimizer2(opt).optimize()
+    ro = o.optimize(iters, 10.0, 1e-4, 1e-5, 2)
+    assert rv.iterations == ro["iterations"] and rv.failedIterations == ro["failedIterations"]
+    assert abs(rv.JFinal - ro["JFinal"]) <= 1e-7 * abs(ro["JFinal"])
+    assert rv.JFinal < 0.1 * rv.JStart
+    for h, v in gids.items():
+        if isinstance(v, int) and sp.ops[h][0] == "dv":
+            a, b = g.dv_params(v), o.dv_params(oids[h])
+            assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max()), (h, a, b)
+    if name == "extrinsic_prior":
+        q = g.dv_params(gids[H["q_i_c"]])
+        qt = quat_from_matrix(H["C_i_c"])
+        assert min(np.abs(q - qt).max(), np.abs(q + qt).max()) < 5e-3
+        assert np.abs(g.dv_params(gids[H["bias"]]) - H["bias_true"]).max() < 5e-3
+
+
+def test_front_end_mirror_lowers_the_initialisation_problems(problems):
+    """The extrinsic-prior problem written statement by statement like findExtrinsicPriorSensorsToCamera
+    (sensors_and_targets.py:858-919) and the target-pose problem like findTargetPosePrior (:803-817), through the
+    front-end mirror, lower to the same problems as the batch description: same pattern, same J, e, H, b."""
+    from multical_amd import frontend as F
+    from oracle_api import OracleApi
+
+    def check(problem, name):
+        sp, _ = F.lower(problem)
+        o2 = OracleApi()
+        sp.emit(o2)
+        o2.finalize()
+        o = problems[name]["oracle"]
+        assert (o2.n_terms, o2.j_rows, o2.j_cols) == (o.n_terms, o.j_rows, o.j_cols)
+        Ja, ea = o.evaluate_error(True)
+        Jb, eb = o2.evaluate_error(True)
+        assert Ja == Jb and np.array_equal(ea, eb)
+        A, B = o.build_system(True), o2.build_system(True)
+        for x, y in zip(A, B):
+            assert np.array_equal(x, y)
+
+    # ---- findExtrinsicPriorSensorsToCamera
+    ops = problems["extrinsic_prior"]["spec"].ops
+    problem = F.OptimizationProblem()
+    dvs = {}
+    for i, (k, d) in enumerate(ops):
+        if k != "dv":
+            continue
+        dv = (F.RotationQuaternionDv if d["kind"] == F.S.DV_ROTATION_QUATERNION else F.EuclideanPointDv)(d["params"])
+        dv.setActive(d["active"])
+        problem.addDesignVariable(dv, d["group"])
+        dvs[i] = dv
+    for i, (k, d) in enumerate(ops):
+        if k == "gyro_prior":
+            R_i_c, bias = dvs[d["dv_q"]].toExpression(), dvs[d["dv_bias"]].toExpression()
+            for j in range(len(d["sinv"])):
+                omega_predicted = R_i_c * F.EuclideanExpression(d["w_pred"][j])
+                problem.addErrorTerm(F.GyroscopeError(d["meas"][j], np.eye(3) * d["sinv"][j] ** 2, omega_predicted, bias))
+        elif k == "transformation":
+            tdv = F.TransformationDv.__new__(F.TransformationDv)
+            tdv.q, tdv.t = dvs[d["dv_q_a"]], dvs[d["dv_t_a"]]
+            tdv.expression = F.TransformationExpression(("t_leaf", tdv.q, tdv.t))
+            for j in range(d["prior_t"].shape[0]):
+                problem.addErrorTerm(F.ErrorTermTransformation(tdv.toExpression(), F.Transformation(d["prior_q"][j], d["prior_t"][j]),
+                                                               d["weight_rotation"], d["weight_translation"]))
+    check(problem, "extrinsic_prior")
+
+    # ---- findTargetPosePrior
+    ops = problems["target_pose_prior"]["spec"].ops
+    problem = F.OptimizationProblem()
+    T_t_w_Dv, by_handle = [], {}
+    dv_ops = [(i, d) for i, (k, d) in enumerate(ops) if k == "dv"]
+    for n in range(0, len(dv_ops), 2):
+        (iq, dq), (it, dt) = dv_ops[n], dv_ops[n + 1]
+        tdv = F.TransformationDv(F.Transformation(dq["params"], dt["params"]), rotationActive=dq["active"], translationActive=dt["active"])
+        for j in range(tdv.numDesignVariables()):
+            problem.addDesignVariable(tdv.getDesignVariable(j), dq["group"])
+        by_handle[iq] = tdv
+        T_t_w_Dv.append(tdv)
+    for i, (k, d) in enumerate(ops):
+        if k == "transformation":
+            T_ti_tj_pre = by_handle[d["dv_q_a"]].toExpression() * by_handle[d["dv_q_b"]].toExpression().inverse()
+            for j in range(d["prior_t"].shape[0]):
+                problem.addErrorTerm(F.ErrorTermTransformation(T_ti_tj_pre, F.Transformation(d["prior_q"][j], d["prior_t"][j]), 1.0, 0.1))
+    check(problem, "target_pose_prior")
+
+    # anything else is refused, not approximated
+    bad = F.OptimizationProblem()
+    tdv = F.TransformationDv(F.Transformation())
+    bad.addErrorTerm(F.ErrorTermTransformation(tdv.toExpression().inverse(), F.Transformation(), 1.0, 0.1))
+    with pytest.raises(F.UnsupportedErrorTerm):
+        F.lower(bad)
