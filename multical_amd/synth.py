@@ -129,6 +129,7 @@ CAM_INTRINSICS = {
     (S.PROJ_PINHOLE, S.DIST_NONE): ([460.0, 460.0, 376.0, 240.0], None),
     (S.PROJ_OMNI, S.DIST_RADTAN): ([1.2, 900.0, 900.0, 376.0, 240.0], [-0.05, 0.01, 2e-4, 2e-5]),
     (S.PROJ_OMNI, S.DIST_NONE): ([1.2, 900.0, 900.0, 376.0, 240.0], None),
+    (S.PROJ_OMNI, S.DIST_EQUI): ([1.2, 900.0, 900.0, 376.0, 240.0], [-0.01, 0.02, -0.01, 0.002]),
     (S.PROJ_DS, S.DIST_NONE): ([-0.2, 0.6, 350.0, 350.0, 376.0, 240.0], None),
 }
 C_CAM_BODY = np.array([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])   # camera z = body x
