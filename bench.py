@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="index into BASELINE.json configs (1, 3 or 4)")
     ap.add_argument("--duration", type=float, default=None, help="override the sequence length per GPU [s]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=5.0)
+    ap.add_argument("--cpu-sample-seconds", type=float, default=10.0)
     ap.add_argument("--solve", action="store_true", help="also time one host sparse Cholesky solve (reported separately)")
     args = ap.parse_args()
 
