@@ -136,6 +136,18 @@ struct Problem {
   std::unordered_map<std::string, int> fp_lookup;
   std::vector<int> update_dvs;              // active dvs in block order
   std::vector<int> ofp_data, ofp_off;       // other-block footprints of the chunks
+  // Contended entries.  Hessian entries between two design variables that are not spline coefficients (extrinsics, time
+  // offsets, target poses, gravity ...) are written by EVERY work item of a sensor stream: thousands of fp64 atomics
+  // queue on the same few cache lines.  The kernels add those entries (and the matching rhs entries) into one of
+  // REP_COPIES replicas of a small dense upper triangle over the "global" scalar columns instead; k_rep_reduce folds the
+  // replicas into Cx / rhs at the end of buildSystem.  gcb[block] = first compact column of the block, -1 for spline
+  // coefficients; disabled (all -1) when there are more than REP_MAX_COLS such columns (camera-calibration problems,
+  // where every view's pose is a design variable and nothing is contended that much).
+  enum { REP_COPIES = 16, REP_MAX_COLS = 512 };
+  std::vector<int> gcb;                     // per block
+  int rep_cols = 0;                         // compact global columns (0: replicas disabled)
+  std::vector<int> rep_idx, rep_addr;       // dense triangle index -> Cx value index, for the pairs present in the pattern
+  std::vector<int> rep_rhs_col;             // compact column -> scalar column of rhs
   // J^T layout of a term of a chunk (SparseCholesky backend): its design variables sorted by block index are the pose
   // buffer range, the 6 live bias coefficients and the single other blocks.  Per ofp, JT_STRIDE ints:
   //   [role]                    constant part of the role's first element index (-1: inactive)
@@ -652,6 +664,36 @@ inline void Problem::finalize() {
         for (int r = 0; r < n; ++r) *ci++ = block_col[rb] + r;
       }
     }
+  // ---- replicas of the contended (global x global) entries
+  gcb.assign(n_blocks, -1);
+  rep_cols = 0; rep_idx.clear(); rep_addr.clear(); rep_rhs_col.clear();
+  {
+    int ng = 0;
+    for (int c = 0; c < n_blocks; ++c) if (dvs[block_dv[c]].kind != DV_SPLINE_COEFF) ng += block_dim[c];
+    if (ng > 0 && ng <= REP_MAX_COLS) {
+      for (int c = 0; c < n_blocks; ++c) {
+        if (dvs[block_dv[c]].kind == DV_SPLINE_COEFF) continue;
+        gcb[c] = rep_cols;
+        for (int sc = 0; sc < block_dim[c]; ++sc) rep_rhs_col.push_back(block_col[c] + sc);
+        rep_cols += block_dim[c];
+      }
+      for (int c = 0; c < n_blocks; ++c) {
+        if (gcb[c] < 0) continue;
+        for (size_t k = 0; k < col_rows[c].size(); ++k) {
+          const int rb = col_rows[c][k];
+          if (gcb[rb] < 0) continue;
+          for (int sc = 0; sc < block_dim[c]; ++sc) {
+            const int n = (rb == c) ? sc + 1 : block_dim[rb];
+            const int gj = gcb[c] + sc;
+            for (int r = 0; r < n; ++r) {
+              rep_idx.push_back(gj * (gj + 1) / 2 + gcb[rb] + r);
+              rep_addr.push_back(Cp[block_col[c] + sc] + col_roff[c][k] + r);
+            }
+          }
+        }
+      }
+    }
+  }
   // ---- block pattern as CSR (device-side slot lookups of the chunk kernels)
   pat_colptr.assign(n_blocks + 1, 0); pat_rows.clear(); pat_roff.clear(); pat_cp0.assign(n_blocks, 0);
   for (int c = 0; c < n_blocks; ++c) {

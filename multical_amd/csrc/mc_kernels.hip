@@ -37,6 +37,11 @@ struct DevCommon {
   const int* pat_roff;
   const int* pat_cp0;
   const int* chunk_tab;  // per-chunk slot tables (Problem::chunk_tab)
+  // replicas of the contended global x global entries (Problem::gcb; null / 0 when disabled)
+  const int* gcb;
+  double* rep;           // REP_COPIES x rep_stride: dense upper triangle over the compact global columns
+  double* rep_rhs;       // REP_COPIES x rep_cols
+  int rep_stride, rep_cols;
   double* Cx;
   double* rhs;
   double* e;        // may be null
@@ -77,6 +82,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+// replica of this workgroup for the contended entries (gi <= gj compact global columns)
+__device__ __forceinline__ double* rep_entry(const DevCommon& dc, int gi, int gj) {
+  return dc.rep + (size_t)(blockIdx.x & (Problem::REP_COPIES - 1)) * dc.rep_stride + (gj * (gj + 1)) / 2 + gi;
+}
+__device__ __forceinline__ double* rep_rhs_entry(const DevCommon& dc, int g) {
+  return dc.rep_rhs + (size_t)(blockIdx.x & (Problem::REP_COPIES - 1)) * dc.rep_cols + g;
+}
 
 // decoded footprint
 struct FpView {
@@ -119,16 +131,18 @@ __device__ __forceinline__ int global_col(const FpView& f, int ca) {
 // transformation chain prefixes).  Done inside k_reproj this would be repeated by every lane of the workgroup -- as
 // many flops as the corners themselves.
 __global__ __launch_bounds__(64) void k_obs_common(const ReprojBatchView* __restrict__ views, const double* __restrict__ x,
-                                                   const GroupRec* __restrict__ groups, int n, F1Common* __restrict__ out) {
+                                                   const GroupRec* __restrict__ groups, int n, F1Common* __restrict__ out,
+                                                   F1Chain* __restrict__ chain) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const GroupRec gr = groups[g];
   F1Common cm;
   f1_common(views[gr.batch], x, gr.aux, cm);
   out[g] = cm;
+  if (chain && cm.ok) f1_chain_matrix(views[gr.batch], cm, chain[g]);   // build passes only
 }
 
-enum { F1_LD = F1_CORE + 2, F1_ROWS = 256 };  // 21: odd stride, conflict-free column reads; 128 corners per pass
+enum { F1_ROWS = 256 };  // corners per pass of k_reproj
 // consecutive observations (groups) of one camera taken at the same time: one image seeing several boards
 struct ImageRec { int first, count; };
 
@@ -143,7 +157,8 @@ __device__ __forceinline__ void f1_live(int p, int ncoef, int rc0, int coef_shif
   else { lc = glc[p - ncoef]; k = gk[p - ncoef]; wt = 1.0; }
 }
 __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, const double* Msh, const double* w, int rc0,
-                                         int coef_shift, const int* glc, const int* gk, int n_nb, int nglob, bool board_part, int tid) {
+                                         int coef_shift, const int* glc, const int* gk, const int* ggc, int n_nb, int nglob,
+                                         bool board_part, int tid) {
   const int ncoef = rc0 >= 0 ? 36 : 0;
   const int nlive = ncoef + nglob, M = ncoef + n_nb;
   const int npair = board_part ? (nlive - M) * nlive : M * (M + 1) / 2;
@@ -162,6 +177,13 @@ __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, c
     f1_live(q, ncoef, rc0, coef_shift, w, glc, gk, lcq, kq_, wq);
     int ka = min(kp_, kq_), kb = max(kp_, kq_);
     double v = wp * wq * Msh[kb * (kb + 1) / 2 + ka];
+    if (p >= ncoef) {   // then q >= ncoef too: both columns belong to global design variables, entries every image writes
+      const int gp = ggc[p - ncoef], gq = ggc[q - ncoef];
+      if (gp >= 0 && gq >= 0) {
+        if (MC_MODE(dc) == 1 || v == 1.2345e-300) atomic_add_f64(rep_entry(dc, min(gp, gq), max(gp, gq)), v);
+        continue;
+      }
+    }
     int ca = min(lcp, lcq), cb = max(lcp, lcq);
     int addr = entry_addr(f, dc.col_h, ca, cb);
     if (MC_MODE(dc) == 1 || v == 1.2345e-300) atomic_add_f64(dc.Cx + addr, v);
@@ -172,26 +194,37 @@ __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, c
     double wp;
     f1_live(p, ncoef, rc0, coef_shift, w, glc, gk, lcp, kp_, wp);
     double v = -wp * Msh[19 * 20 / 2 + kp_];
-    if (MC_MODE(dc) == 1 || v == 1.2345e-300) atomic_add_f64(dc.rhs + global_col(f, lcp), v);
+    const int gp = p >= ncoef ? ggc[p - ncoef] : -1;
+    if (MC_MODE(dc) == 1 || v == 1.2345e-300) atomic_add_f64(gp >= 0 ? rep_rhs_entry(dc, gp) : dc.rhs + global_col(f, lcp), v);
   }
 }
 
+#ifndef MC_REPROJ_OCC
+#define MC_REPROJ_OCC 3
+#endif
 template <bool BUILD>
-__global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
+__global__ __launch_bounds__(256, BUILD ? MC_REPROJ_OCC : 1) void k_reproj(const ReprojBatchView* __restrict__ views, DevCommon dc,
                                                 const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
-                                                const F1Common* __restrict__ common, int jpart_base) {
-  // One 256-thread workgroup per IMAGE; its observations (one per visible board) are processed one after the other.
-  // build: thread = one residual ROW (two threads per corner), so the Jacobian phase, the 20 x 20 core Gram and the
-  // expansion all run four waves wide.  The observations of an image share time, camera and extrinsics, so the part of
-  // their core Gram that does not involve the board pose is summed over the image and flushed ONCE; only the board
-  // rows / columns are flushed per observation (about 3x fewer atomics at ~4 boards per image).
-  __shared__ double rows[F1_ROWS * F1_LD];
+                                                const F1Common* __restrict__ common, const F1Chain* __restrict__ chain,
+                                                int jpart_base) {
+  // One 256-thread workgroup per IMAGE; its observations (one per visible board) are processed one after the other,
+  // thread = corner.  build: below the camera the chain rule is linear in z = [a, a x p_c] (a = weighted row of -J_cam),
+  // core row = z K with K (6 x 19) fixed per observation (f1_chain_matrix, computed by the pre-pass).  So a corner only
+  // contributes its two 7-vectors [z | residual]; the workgroup reduces their 7 x 7 Gram on the fp64 matrix cores and
+  // forms the 20 x 20 core Gram  [K 0; 0 1]^T G [K 0; 0 1]  once per observation.  The observations of an image share
+  // time, camera and extrinsics, so the part of the core Gram that does not involve the board pose is summed over the
+  // image and flushed ONCE; only the board rows / columns are flushed per observation.
+  enum { ZLD = 2 * F1_ROWS + 4 };   // 516: column stride of the z tile; 2 * 516 mod 64 = 8 -> the 7 columns x 4 rows an MFMA
+                                    // step reads fall into distinct banks
+  __shared__ double zs[BUILD ? 7 * ZLD : 1];   // z tile, column major: zs[c * ZLD + residual row]
+  __shared__ double Gs[49], Ts[140];
   __shared__ double Msh[210];
-  __shared__ int glc[13], gk[13];
+  __shared__ int glc[13], gk[13], ggc[13];
   __shared__ double red[4];
   // the per-observation quantities (k_obs_common) are uniform over the workgroup: parked in LDS and read back by
   // broadcast so they do not occupy ~110 vector registers per lane
   __shared__ F1Common cm;
+  __shared__ double Ks[BUILD ? 6 * F1_CORE : 1];
   // the footprint table (block list, value offsets of every block pair) is staged too: the expansion turns
   // ~1600 (column, column) pairs into addresses and would otherwise chase 3 dependent global loads per pair
   enum { FP_LDS = 768 };
@@ -213,18 +246,19 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
   int last_rc0 = -1, last_shift = 0, last_nnb = 0;
   bool last_staged = false;
   int last_fp_begin = 0;
-  // build: two threads per corner (one residual row each); evaluate only: one thread per corner
-  constexpr int CPP = BUILD ? F1_ROWS / 2 : F1_ROWS;   // corners per pass
-  const int r = BUILD ? (tid & 1) : 0;
+  constexpr int CPP = F1_ROWS;   // corners per pass
   // The per-observation record and footprint of observation go + 1 are fetched into registers while observation go is
   // being processed (the barriers below only wait for LDS, so the loads stay in flight across them).
-  static_assert(sizeof(F1Common) % 8 == 0 && sizeof(F1Common) / 8 <= 256, "F1Common is copied as doubles, one per thread");
+  constexpr int NCM = (int)(sizeof(F1Common) / 8), NCK = 6 * F1_CORE;
+  static_assert(sizeof(F1Common) % 8 == 0 && NCM <= 128 && 128 + NCK <= 256, "record: threads 0..NCM-1, chain matrix: threads 128..128+NCK-1");
+  static_assert(sizeof(F1Chain) == NCK * 8, "F1Chain is copied as doubles");
   double pf_cm = 0.0;
   int pf_fp[FP_LDS / 256] = {0, 0, 0};
   GroupRec gr_next = groups[im.first];
   int fpb_next = dc.fp_off[gr_next.fp], fpl_next = dc.fp_off[gr_next.fp + 1] - fpb_next;
   auto prefetch = [&](int gi, int fp_begin, int fp_len) {
-    if (tid < (int)(sizeof(F1Common) / 8)) pf_cm = reinterpret_cast<const double*>(common + gi)[tid];
+    if (tid < NCM) pf_cm = reinterpret_cast<const double*>(common + gi)[tid];
+    else if (BUILD && tid >= 128 && tid < 128 + NCK) pf_cm = chain[gi].K[tid - 128];
     if (BUILD && fp_len <= FP_LDS) {
 #pragma unroll
       for (int j = 0; j < FP_LDS / 256; ++j) if (tid + 256 * j < fp_len) pf_fp[j] = dc.fp_data[fp_begin + tid + 256 * j];
@@ -239,9 +273,10 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
     const ReprojBatchView b = views[gr.batch];
     const int fp_begin = fpb_next, fp_len = fpl_next;
     const bool fp_staged = BUILD && fp_len <= FP_LDS;
-    __syncthreads();   // previous observation's flush is done with cm / fpl / Msh
+    __syncthreads();   // previous observation's flush is done with cm / Ks / fpl / Msh
     {
-      if (tid < (int)(sizeof(F1Common) / 8)) reinterpret_cast<double*>(&cm)[tid] = pf_cm;
+      if (tid < NCM) reinterpret_cast<double*>(&cm)[tid] = pf_cm;
+      else if (BUILD && tid >= 128 && tid < 128 + NCK) Ks[tid - 128] = pf_cm;
       if (fp_staged) {
 #pragma unroll
         for (int j = 0; j < FP_LDS / 256; ++j) if (tid + 256 * j < fp_len) fpl[tid + 256 * j] = pf_fp[j];
@@ -280,76 +315,98 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
         else if (tid < 10) { role = F1_ROLE_QPW; d = tid - 7; pos = n_nb; kcore = 12 + d; }
         else { role = F1_ROLE_TPW; d = tid - 10; pos = n_nb + 3 * a_qpw; kcore = 15 + d; }
         const int rc = f.rolecol[role];
-        if (rc >= 0) { glc[pos + d] = rc + d; gk[pos + d] = kcore; }
+        if (rc >= 0) {
+          glc[pos + d] = rc + d; gk[pos + d] = kcore;
+          const int g = dc.rep ? dc.gcb[f.blocks[4 * f.colblk[rc]]] : -1;   // compact global column (contended-entry replicas)
+          ggc[pos + d] = g >= 0 ? g + d : -1;
+        }
       }
     }
-    f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0};
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     for (int base = 0; base < gr.term_count; base += CPP) {
-      const int k = base + (BUILD ? (tid >> 1) : tid);
+      const int k = base + tid;
       const int nrows = 2 * min(CPP, gr.term_count - base);
+      if (BUILD && base > 0) __syncthreads();   // the previous pass's MFMA reads of zs are done
       if (k < gr.term_count) {
         const int term = gr.term_first + k;
         double pc[3], Jc[6], e[2], sw;
         TermOut out;
         f1_project(b, dc.x, cm, term, dc.useM != 0, BUILD, pc, Jc, e, sw, out);
-        const double er = r ? e[1] : e[0];
-        if (r == 0) { Jacc += out.w * out.chi2; dc.chi2[b.term_base_global + term] = out.chi2; }
-        if (dc.e) {
-          if (BUILD) dc.e[b.row_base + 2 * term + r] = -er;
-          else { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
-        }
+        Jacc += out.w * out.chi2;
+        dc.chi2[b.term_base_global + term] = out.chi2;
+        if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
         if (BUILD) {
-          double jc[3] = {r ? Jc[3] : Jc[0], r ? Jc[4] : Jc[1], r ? Jc[5] : Jc[2]};
-          double* row = rows + tid * F1_LD;
-          f1_chain_row(b, cm, jc, sw, pc, row);
-          row[F1_CORE] = er;
+          // A0 = -J_cam through HomogeneousExpressionNodeMultiply: [a, a x p_c]; both residual rows of the corner side by
+          // side, one 16-byte LDS store per column
+          const double a0[3] = {-sw * Jc[0], -sw * Jc[1], -sw * Jc[2]}, a1[3] = {-sw * Jc[3], -sw * Jc[4], -sw * Jc[5]};
+          double c0[3], c1[3];
+          v3_cross(a0, pc, c0);
+          v3_cross(a1, pc, c1);
+          double2* zp = reinterpret_cast<double2*>(zs + 2 * tid);   // ZLD is even: 16-byte aligned
+          constexpr int Z2 = ZLD / 2;
+          zp[0 * Z2] = make_double2(a0[0], a1[0]); zp[1 * Z2] = make_double2(a0[1], a1[1]); zp[2 * Z2] = make_double2(a0[2], a1[2]);
+          zp[3 * Z2] = make_double2(c0[0], c1[0]); zp[4 * Z2] = make_double2(c0[1], c1[1]); zp[5 * Z2] = make_double2(c0[2], c1[2]);
+          zp[6 * Z2] = make_double2(e[0], e[1]);
         }
       }
-      MC_MARK(1);   // projection + chain rows
+      MC_MARK(1);   // projection + z rows
       if (BUILD) {
-        // 20 x 20 core Gram R^T R on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A[i][k] = R[k][i] and
-        // B[k][j] = R[k][j] one double per lane (lane = 16 (k % 4) + column), so a K-step of 4 rows costs two LDS
-        // reads and three MFMAs (column tiles 0..15 and 16..19: blocks 00, 01, 11).  The 4 waves take every 4th K-step.
+        // 7 x 7 Gram Z^T Z on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A[i][k] = Z[k][i] and B[k][j] = Z[k][j]
+        // one double per lane (lane = 16 (k % 4) + column), so a K-step of 4 rows is one LDS read and one MFMA.  The 4
+        // waves take every 4th K-step.
         __syncthreads();
         MC_MARK(2); // waiting for the other waves' rows
         const int lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
         const int nsteps = (nrows + 3) >> 2;
         for (int st = tid >> 6; st < nsteps; st += 4) {
           const int rr = 4 * st + kr;
-          double v0 = 0.0, v1 = 0.0;
-          if (rr < nrows) { v0 = rows[rr * F1_LD + c16]; if (c16 < 4) v1 = rows[rr * F1_LD + 16 + c16]; }
-          acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc00, 0, 0, 0);
-          acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, acc01, 0, 0, 0);
-          acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc11, 0, 0, 0);
+          const double v = (c16 < 7 && rr < nrows) ? zs[c16 * ZLD + rr] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
         }
-        __syncthreads();
         MC_MARK(3); // MFMA Gram
       }
     }
     if (BUILD) {
-      // per-wave partial tiles -> LDS (aliasing the row tile, which is dead now) -> one entry per thread.
-      // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
-      double* stage = rows;   // [wave][tile][reg][lane]
+      // per-wave partial tiles -> LDS (aliasing the z tile, which is dead after the barrier) -> G (49 threads) -> the
+      // 20 x 20 core Gram, one entry per thread.  C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
+      __syncthreads();
+      double* stage = zs;   // [wave][reg][lane]; only rows 0..6 (reg 0, 1) are needed
       const int wv = tid >> 6, lane = tid & 63;
+      stage[(wv * 2 + 0) * 64 + lane] = acc[0];
+      stage[(wv * 2 + 1) * 64 + lane] = acc[1];
+      __syncthreads();
+      if (tid < 49) {
+        const int i = tid / 7, j = tid - 7 * i;
+        const int off = (i >> 2) * 64 + (i & 3) * 16 + j;
+        Gs[tid] = stage[off] + stage[off + 128] + stage[off + 256] + stage[off + 384];
+      }
+      __syncthreads();
+      // M = Kt^T G Kt with Kt = [K 0; 0 1] (7 x 20), in two steps of 7 multiply-adds per thread: T = G Kt (7 x 20), M = Kt^T T
+      if (tid < 140) {
+        const int i = tid / 20, c = tid - 20 * i;
+        double t = Gs[i * 7 + 6];
+        if (c < F1_CORE) {
+          t = 0.0;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        stage[((wv * 3 + 0) * 4 + rg) * 64 + lane] = acc00[rg];
-        stage[((wv * 3 + 1) * 4 + rg) * 64 + lane] = acc01[rg];
-        stage[((wv * 3 + 2) * 4 + rg) * 64 + lane] = acc11[rg];
+          for (int j = 0; j < 6; ++j) t += Gs[i * 7 + j] * Ks[j * F1_CORE + c];
+        }
+        Ts[tid] = t;
       }
       __syncthreads();
       if (tid < 210) {
-        const int t = ea >= 16 ? 2 : (eb >= 16 ? 1 : 0);
-        const int i = ea & 15, j = eb & 15;
-        const int off = (t * 4 + (i >> 2)) * 64 + (i & 3) * 16 + j;
-        const double m = stage[off] + stage[off + 768] + stage[off + 2 * 768] + stage[off + 3 * 768];
+        double m = Ts[6 * 20 + eb];
+        if (ea < F1_CORE) {
+          m = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) m += Ks[i * F1_CORE + ea] * Ts[i * 20 + eb];
+        }
         Msh[tid] = m;
         if (!my_board_entry) img_acc += m;
       }
       __syncthreads();
-      MC_MARK(4);   // tiles -> Msh
+      MC_MARK(4);   // tiles -> G -> Msh
       // board rows / columns of this observation
-      if (MC_MODE(dc) != 3) f1_flush(f, dc, Msh, cm.w, rc0, coef_shift, glc, gk, n_nb, n_glob, true, tid);
+      if (MC_MODE(dc) != 3) f1_flush(f, dc, Msh, cm.w, rc0, coef_shift, glc, gk, ggc, n_nb, n_glob, true, tid);
       last_nnb = n_nb;
       MC_MARK(5);   // board flush
       any_done = true; last_rc0 = rc0; last_shift = coef_shift; last_staged = fp_staged; last_fp_begin = fp_begin;
@@ -365,7 +422,7 @@ __global__ __launch_bounds__(256, BUILD ? 3 : 1) void k_reproj(const ReprojBatch
   if (tid < 210) Msh[tid] = img_acc;
   __syncthreads();
   FpView f = last_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + last_fp_begin);
-  f1_flush(f, dc, Msh, cm.w, last_rc0, last_shift, glc, gk, last_nnb, last_nnb, false, tid);
+  f1_flush(f, dc, Msh, cm.w, last_rc0, last_shift, glc, gk, ggc, last_nnb, last_nnb, false, tid);
   MC_MARK(6);   // image flush
 }
 
@@ -636,8 +693,15 @@ __global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restr
     }
     if (acc == 0.0 || MC_MODE(dc) != 1) continue;
     const int o1 = ocolblk[g1], s1 = g1 - oinfo[3 * o1 + 1];
-    if (g2 == G) { atomic_add_f64(dc.rhs + oinfo[3 * o1 + 2] + s1, -acc); continue; }
+    // entries between two global design variables (extrinsics, time offset, target poses, gravity ...) are written by every
+    // chunk of the stream: they go to this workgroup's replica (folded into Cx / rhs by k_rep_reduce)
+    const int gb1 = dc.rep ? dc.gcb[oinfo[3 * o1]] : -1;
+    if (g2 == G) { atomic_add_f64(gb1 >= 0 ? rep_rhs_entry(dc, gb1 + s1) : dc.rhs + oinfo[3 * o1 + 2] + s1, -acc); continue; }
     const int o2 = ocolblk[g2], s2 = g2 - oinfo[3 * o2 + 1];
+    if (gb1 >= 0) {
+      const int gb2 = dc.gcb[oinfo[3 * o2]];
+      if (gb2 >= 0) { atomic_add_f64(rep_entry(dc, min(gb1 + s1, gb2 + s2), max(gb1 + s1, gb2 + s2)), acc); continue; }
+    }
     if (o1 == o2) {
       int slot = oo_slot[o1 * nob + o1];
       if (slot >= 0) atomic_add_f64(dc.Cx + slot + s2 * oh[o1] + (s2 * (s2 + 1)) / 2 + s1, acc);
@@ -1101,6 +1165,26 @@ __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ part, in
 }
 
 // multi-GPU combination: gather / scatter of the value entries that more than one rank writes
+// folds the replicas of the contended entries into Cx / rhs (runs after every build kernel has finished)
+__global__ __launch_bounds__(256) void k_rep_reduce(const int* __restrict__ idx, const int* __restrict__ addr, int n,
+                                                    const double* __restrict__ rep, int stride, double* __restrict__ Cx,
+                                                    const int* __restrict__ rhs_col, int ncols, const double* __restrict__ rep_rhs,
+                                                    double* __restrict__ rhs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int k = idx[i];
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < Problem::REP_COPIES; ++r) s += rep[(size_t)r * stride + k];
+    Cx[addr[i]] += s;
+  } else if (i < n + ncols) {
+    const int g = i - n;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < Problem::REP_COPIES; ++r) s += rep_rhs[(size_t)r * ncols + g];
+    rhs[rhs_col[g]] += s;
+  }
+}
 __global__ __launch_bounds__(256) void k_pack(const int* __restrict__ idx, int n, const double* __restrict__ src, double* __restrict__ dst) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
@@ -1231,6 +1315,7 @@ struct LaunchUnit {
   DevBuf<TransformBatchView> tviews;
   DevBuf<F2Common> common2;  // F2: per observation, rewritten by k_static_common before every k_static
   DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
+  DevBuf<F1Chain> chain;     // per image observation: matrix of the chain below the camera (build passes)
   DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time; F2: runs of observations of one camera
   int n_images = 0;
   int static_ld = 0;         // F2: row stride of the LDS tile
@@ -1246,6 +1331,9 @@ struct mc_context {
   int device = 0;
   DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, Jpart2, J, dx;
   DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab, shared_idx;
+  DevBuf<int> gcb, rep_idx, rep_addr, rep_rhs_col;
+  DevBuf<double> rep;   // REP_COPIES x (triangle + rep_cols): matrix replicas, then rhs replicas
+  int rep_stride = 0;
   DevBuf<UpdRec> upd;
   DevBuf<long long> jt_start;
   DevBuf<int> jt_epc, ofp_jt;
@@ -1337,6 +1425,12 @@ void mc_context::uploadStructure() {
   fp_off.upload(P.fp_off);
   col_h.upload(P.col_h);
   ofp_data.upload(P.ofp_data); ofp_off.upload(P.ofp_off);
+  rep_stride = 0;
+  if (P.rep_cols > 0 && std::getenv("MC_NO_REPLICAS") == nullptr) {
+    gcb.upload(P.gcb); rep_idx.upload(P.rep_idx); rep_addr.upload(P.rep_addr); rep_rhs_col.upload(P.rep_rhs_col);
+    rep_stride = P.rep_cols * (P.rep_cols + 1) / 2;
+    rep.alloc((size_t)Problem::REP_COPIES * (rep_stride + P.rep_cols));
+  }
   pat_colptr.upload(P.pat_colptr); pat_rows.upload(P.pat_rows); pat_roff.upload(P.pat_roff); pat_cp0.upload(P.pat_cp0);
   chunk_tab.upload(P.chunk_tab);
   shared_idx.upload(P.shared_idx);
@@ -1560,6 +1654,7 @@ void mc_context::uploadStructure() {
       L.n_jpart = L.n_items;
       if (l == LAUNCH_REPROJ) {
         L.common.alloc(groups[l].size());
+        L.chain.alloc(groups[l].size());
         L.images.upload(images);
         L.n_images = (int)images.size();
         L.n_jpart = L.n_images;
@@ -1596,9 +1691,15 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   dc.Cx = dCx; dc.rhs = dRhs; dc.e = dE; dc.chi2 = chi2.p; dc.Jpart = Jpart.p; dc.status = status.p;
   dc.useM = useM; dc.build = build;
   dc.phase = phase_on ? phase.p : nullptr;
+  const bool use_rep = build && rep_stride > 0;
+  dc.gcb = use_rep ? gcb.p : nullptr;
+  dc.rep = use_rep ? rep.p : nullptr;
+  dc.rep_rhs = use_rep ? rep.p + (size_t)Problem::REP_COPIES * rep_stride : nullptr;
+  dc.rep_stride = rep_stride; dc.rep_cols = P.rep_cols;
   if (build) {
     HIP_CHECK(hipMemsetAsync(dCx, 0, sizeof(double) * P.nnz, st));
     HIP_CHECK(hipMemsetAsync(dRhs, 0, sizeof(double) * P.j_cols, st));
+    if (use_rep) HIP_CHECK(hipMemsetAsync(rep.p, 0, sizeof(double) * (size_t)Problem::REP_COPIES * (rep_stride + P.rep_cols), st));
   }
   if (dE && P.world > 1) HIP_CHECK(hipMemsetAsync(dE, 0, sizeof(double) * P.j_rows, st));
   // per-launch timing (ev) needs the launches back to back on one stream
@@ -1619,9 +1720,10 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     }
     switch (l) {
       case LAUNCH_REPROJ:
-        hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p);
-        if (build) hipLaunchKernelGGL(k_reproj<true>, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
-        else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
+        hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
+                           build ? L.chain.p : nullptr);
+        if (build) hipLaunchKernelGGL(k_reproj<true>, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.chain.p, L.jpart_base);
+        else hipLaunchKernelGGL(k_reproj<false>, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.chain.p, L.jpart_base);
         break;
       case LAUNCH_STATIC:
         hipLaunchKernelGGL(k_static_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.sviews.p, x.p, L.groups.p, L.n_items, L.common2.p);
@@ -1659,6 +1761,12 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   for (int s = 0; s < N_SIDE; ++s)
     if (used[s]) { HIP_CHECK(hipEventRecord(ev_join[s], side[s])); HIP_CHECK(hipStreamWaitEvent(st, ev_join[s], 0)); }
   if (ev) HIP_CHECK(hipEventRecord((*ev)[N_LAUNCH], st));
+  if (use_rep) {
+    const int n = (int)P.rep_idx.size();
+    hipLaunchKernelGGL(k_rep_reduce, dim3((n + P.rep_cols + 255) / 256), dim3(256), 0, st, rep_idx.p, rep_addr.p, n, dc.rep, rep_stride, dCx,
+                       rep_rhs_col.p, P.rep_cols, dc.rep_rhs, dRhs);
+    HIP_CHECK(hipGetLastError());
+  }
   if (!build || dJ) {
     double* out = dJ ? dJ : J.p;
     int nblk = std::min(256, std::max(1, n_jpart / 1024));
@@ -1684,7 +1792,8 @@ void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
   HIP_CHECK(hipMemsetAsync(dValues, 0, sizeof(double) * (size_t)P.jt_nnz, st));
   if (lu[LAUNCH_REPROJ].n_items) {
     LaunchUnit& L = lu[LAUNCH_REPROJ];
-    hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p);
+    hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
+                       (F1Chain*)nullptr);
     hipLaunchKernelGGL(k_jt_reproj, dim3(L.n_items), dim3(64), 0, st, L.rviews.p, dc, L.groups.p, L.common.p, jt);
   }
   if (lu[LAUNCH_STATIC].n_items) {

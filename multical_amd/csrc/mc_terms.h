@@ -164,12 +164,10 @@ MC_HD void f1_project(const ReprojBatchView& b, const double* x, const F1Common&
   sw = (useM ? sqrt(out.w) : 1.0) * s;
   e[0] = sw * e0; e[1] = sw * e1;
 }
-// One corner, second half: one weighted core row (19 values) from one row jc[3] of the projection Jacobian.
-MC_HD void f1_chain_row(const ReprojBatchView& b, const F1Common& cm, const double* jc, double sw, const double* pc, double* row) {
-  // A0 = -J_cam; through HomogeneousExpressionNodeMultiply: A1 = A0 * boxMinus(p_c) = [a, a x p_c]
-  double a[3] = {-sw * jc[0], -sw * jc[1], -sw * jc[2]};
-  double ap[3];
-  v3_cross(a, pc, ap);
+// The chain below the camera is LINEAR in z = [a, a x p_c] (a = one weighted row of -J_cam): every node between the
+// homogeneous point and the leaves multiplies the incoming 1 x 6 row by a matrix that only depends on the observation
+// (T_c_p, X, r, S, the lever arms).  f1_chain_lin is that linear map, z -> 19 core columns.
+MC_HD void f1_chain_lin(const ReprojBatchView& b, const F1Common& cm, const double* a, const double* ap, double* row) {
   // lhs of (X * T_w_p), lhs of (T_c_b * T_b_w): TransformationBasic(q_c_b, t_c_b)
   chain_basic(a, ap, cm.rcb, row + 6, row + 9);
 #pragma unroll
@@ -197,6 +195,26 @@ MC_HD void f1_chain_row(const ReprojBatchView& b, const F1Common& cm, const doub
   row[18] = jd * b.toff.scale;
 #pragma unroll
   for (int d = 0; d < 6; ++d) row[d] = B[d] * b.coef_scale;
+}
+// One corner, second half: one weighted core row (19 values) from one row jc[3] of the projection Jacobian.
+MC_HD void f1_chain_row(const ReprojBatchView& b, const F1Common& cm, const double* jc, double sw, const double* pc, double* row) {
+  // A0 = -J_cam; through HomogeneousExpressionNodeMultiply: A1 = A0 * boxMinus(p_c) = [a, a x p_c]
+  double a[3] = {-sw * jc[0], -sw * jc[1], -sw * jc[2]};
+  double ap[3];
+  v3_cross(a, pc, ap);
+  f1_chain_lin(b, cm, a, ap, row);
+}
+// The matrix of f1_chain_lin, K (6 x 19, row major): core row = z K.  With it the 19 x 19 core Gram of an observation is
+// K^T (sum_rows z^T z) K, so the build kernel reduces a 7 x 7 Gram of [z | residual] per observation and applies K once
+// instead of pushing every residual row through the chain.
+struct F1Chain { double K[6 * F1_CORE]; };
+MC_HD void f1_chain_matrix(const ReprojBatchView& b, const F1Common& cm, F1Chain& ck) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    z[i] = 1.0;
+    f1_chain_lin(b, cm, z, z + 3, ck.K + i * F1_CORE);
+  }
 }
 // One corner: weighted core rows (2 x 19, row stride ld) and weighted residual e[2].
 MC_HD void f1_term(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,
