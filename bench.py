@@ -143,12 +143,23 @@ def main():
             continue
         per_kernel[name] = dict(ms=float(mb), eval_ms=float(me), launches=1, flops_dense=fd, flops_live=fl, rec_bytes=rb,
                                 terms=nt, workgroups=nwg)
+    # buildSystem alone, as launched in the step (term families on their own streams)
+    fence()
+    t3 = time.perf_counter()
+    for _ in range(args.steps):
+        api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), stream)
+    fence()
+    build_wall_ms = (time.perf_counter() - t3) / args.steps * 1e3
     dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
     pk = per_kernel[dom]
     avg_launch_ms = pk["ms"] / max(1, pk["launches"])
-    # algorithmic bytes of this kernel's launches: records + the Hessian / gradient entries it must produce + the state
+    # SURVEY 8(d) algorithmic bytes of one buildSystem: term records + the Hessian / gradient entries it must produce + the
+    # state, read once.  The dominant kernel's share of the Hessian / state bytes is taken in proportion to its records.
     state_bytes = 8.0 * sum(d["params"].size if k == "dv" else d["coeffs"].size for k, d in spec.ops if k in ("dv", "spline"))
-    alg_bytes = pk["rec_bytes"] + (8.0 * (api.nnz + api.j_cols) + state_bytes) * (pk["ms"] / max(1e-9, float(ms_build.sum())))
+    rec_total = sum(v["rec_bytes"] for v in per_kernel.values())
+    out_bytes = 8.0 * (api.nnz + api.j_cols) + state_bytes
+    alg_total = rec_total + out_bytes
+    alg_bytes = pk["rec_bytes"] + out_bytes * pk["rec_bytes"] / max(1.0, rec_total)
     tf_dense = pk["flops_dense"] / (pk["ms"] * 1e-3) / 1e12
     tf_live = pk["flops_live"] / (pk["ms"] * 1e-3) / 1e12
     gbs = alg_bytes / (pk["ms"] * 1e-3) / 1e9
@@ -162,13 +173,18 @@ def main():
         if dom in tj.get("kernels", {}):
             traffic = tj["kernels"][dom]["fetch"] + tj["kernels"][dom]["write"]
             traffic_src = "profiles/%s_pmc_hbm_traffic.csv" % tj["tag"]
-    roofline = dict(bound="mfma", kernel=dom, achieved=round(tf_dense, 4), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(tf_dense / FP64_PEAK_TFLOPS, 5), traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes=round(alg_bytes),
-                    note="fp64 vector/matrix peak; 'achieved' counts the reference's dense per-term J^T J flops (SURVEY 8d)",
-                    achieved_live_flops=round(tf_live, 4), frac_live=round(tf_live / FP64_PEAK_TFLOPS, 5),
-                    hbm_achieved_gbs=round(gbs, 2), hbm_frac=round(gbs / HBM_PEAK_GBS, 5),
-                    avg_launch_ms=round(avg_launch_ms, 4), launches_per_step=pk["launches"],
+    # The kernels execute far fewer flops than the reference's per-term dense J^T J (shared chain matrix, 7 x 7 Gram per
+    # observation, structural zeros skipped), so their floor is the HBM roofline; the fp64 rates of the REFERENCE's flop
+    # count are reported beside it for SURVEY 8(d) and can exceed the fp64 peak.
+    roofline = dict(bound="hbm", kernel=dom, achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_bytes=round(alg_bytes), avg_launch_ms=round(avg_launch_ms, 4), launches_per_step=pk["launches"],
+                    build_system=dict(algorithmic_bytes=round(alg_total), wall_ms=round(build_wall_ms, 4),
+                                      achieved=round(alg_total / (build_wall_ms * 1e-3) / 1e9, 2),
+                                      frac=round(alg_total / (build_wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
+                    fp64=dict(peak_tflops=FP64_PEAK_TFLOPS, reference_dense_tflops=round(tf_dense, 3), reference_live_tflops=round(tf_live, 3),
+                              note="flops of the reference algorithm (dense per-term J^T J incl. padded zero blocks / live blocks only) "
+                                   "divided by this kernel's time; the kernel itself executes a small fraction of them"),
                     kernels_ms={k: round(v["ms"], 4) for k, v in per_kernel.items()},
                     eval_kernels_ms={k: round(v["eval_ms"], 4) for k, v in per_kernel.items()})
 
@@ -178,7 +194,7 @@ def main():
                config=dict(workload="BASELINE configs[%d]: %d IMUs + %d cameras + %d LiDARs, %d boards, time offsets, %.0f s per GPU"
                            % (args.config, cfg.n_imus, cfg.n_cams, cfg.n_lidars, cfg.n_boards, per_gpu),
                            error_terms=n_terms, j_rows=api.j_rows, j_cols=api.j_cols, nnz_upper=api.nnz, n_blocks=api.n_blocks,
-                           build_ms=round(float(ms_build.sum()), 4), evaluate_ms=round(float(ms_eval.sum()), 4),
+                           build_ms=round(build_wall_ms, 4), build_kernels_serial_ms=round(float(ms_build.sum()), 4), evaluate_ms=round(float(ms_eval.sum()), 4),
                            fused_evaluate_and_build_ms=round(dt_fused / args.steps * 1e3, 4),
                            setup_s=round(t_setup, 2), shared_values=n_shared,
                            sharding="time windows, global pattern; RCCL all-reduce of rhs, J and the Cx entries shared between ranks" if world > 1 else "none"),
