@@ -262,6 +262,10 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef MC_RB_OCC
 #define MC_RB_OCC 3
 #endif
+// EQUI / EXPW: whether any camera of the launch has the equidistant distortion (atan) / any batch the Blake-Zisserman
+// weight (exp).  Without them the kernel fits its register budget; with them the compiler parks their polynomial
+// constants in scratch (188 bytes per lane, written by every thread: 460 MB of HBM writes per launch on configs[3]).
+template <bool EQUI, bool EXPW>
 __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBatchView* __restrict__ views, DevCommon dc,
                                                          const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
                                                          const F1Common* __restrict__ common, const F1Chain* __restrict__ chain,
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
         const int term = gr.term_first + k;
         double pc[3], Jc[6], e[2], sw;
         TermOut out;
-        f1_project(b, dc.x, cm, term, dc.useM != 0, true, pc, Jc, e, sw, out);
+        f1_project<EQUI, EXPW>(b, dc.x, cm, term, dc.useM != 0, true, pc, Jc, e, sw, out);
         Jacc += out.w * out.chi2;
         dc.chi2[b.term_base_global + term] = out.chi2;
         if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
@@ -531,8 +535,11 @@ template <> struct StreamTraits<ImuSmBatchView> {
   }
 };
 
+#ifndef MC_STREAM_OCC
+#define MC_STREAM_OCC 1
+#endif
 template <class View, bool BUILD>
-__global__ __launch_bounds__(256) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
+__global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
                                                 const ChunkRec* __restrict__ chunks, StreamDims dm, int jpart_base) {
   extern __shared__ double smem[];
   constexpr int D = StreamTraits<View>::D;
@@ -1319,6 +1326,7 @@ struct LaunchUnit {
   DevBuf<F2Common> common2;  // F2: per observation, rewritten by k_static_common before every k_static
   DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
   DevBuf<F1Chain> chain;     // per image observation: matrix of the chain below the camera (build passes)
+  bool reproj_equi = false, reproj_expw = false;   // any equidistant camera / any Blake-Zisserman batch in the launch
   DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time; F2: runs of observations of one camera
   int n_images = 0;
   int static_ld = 0;         // F2: row stride of the LDS tile
@@ -1672,6 +1680,10 @@ void mc_context::uploadStructure() {
     }
     n_jpart += L.n_jpart;
   }
+  for (const ReprojBatchView& v : rviews) {
+    if (v.cam.dist == MC_DIST_EQUI) lu[LAUNCH_REPROJ].reproj_equi = true;
+    if (v.mest == MC_MEST_BLAKE_ZISSERMAN) lu[LAUNCH_REPROJ].reproj_expw = true;
+  }
   lu[LAUNCH_REPROJ].rviews.upload(rviews);
   lu[LAUNCH_STATIC].sviews.upload(sviews);
   lu[LAUNCH_IMU].iviews.upload(iviews);
@@ -1725,7 +1737,11 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
       case LAUNCH_REPROJ:
         hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
                            build ? L.chain.p : nullptr);
-        if (build) hipLaunchKernelGGL(k_reproj_build, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.chain.p, L.jpart_base);
+        if (build) {
+          auto kb = L.reproj_equi ? (L.reproj_expw ? k_reproj_build<true, true> : k_reproj_build<true, false>)
+                                  : (L.reproj_expw ? k_reproj_build<false, true> : k_reproj_build<false, false>);
+          hipLaunchKernelGGL(kb, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.chain.p, L.jpart_base);
+        }
         else hipLaunchKernelGGL(k_reproj_eval, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
         break;
       case LAUNCH_STATIC:

@@ -303,6 +303,8 @@ struct CameraView {
 // distort(y) and d distort/dy (row-major 2x2 in Jd), CAM/RadialTangentialDistortion.hpp:4-65,
 // CAM/EquidistantDistortion.hpp:4-183 (Jacobian = derivative of y*thetad(atan r)/r, which is what the
 // reference's MATLAB-generated expression evaluates; no r>1e-8 guard on it, like the reference).
+// EQUI = false compiles the equidistant branch (sqrt, atan) out: for launches that hold no such camera
+template <bool EQUI = true>
 MC_HD void distort(int kind, const double* k, double* y, double* Jd) {
   if (kind == 1) {
     double k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3];
@@ -318,7 +320,7 @@ MC_HD void distort(int kind, const double* k, double* y, double* Jd) {
     double y0 = y[0], y1 = y[1];
     y[0] = y0 + y0 * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2);
     y[1] = y1 + y1 * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2);
-  } else if (kind == 2) {
+  } else if (EQUI && kind == 2) {
     double r2 = y[0] * y[0] + y[1] * y[1];
     double r = sqrt(r2);
     double th = atan(r);
@@ -358,13 +360,14 @@ MC_HD void distort_param_jacobian(int kind, const double* y, double* J) {
 // field-of-view test before writing anything (the error terms ignore the flag and read an uninitialised
 // keypoint), keypoint and Jacobian are defined as zero.
 // CAM/PinholeProjection.hpp:73-145, OmniProjection.hpp:72-180, DoubleSphereProjection.hpp:90-221.
+template <bool EQUI = true>
 MC_HD void project(int model, int dist, const double* pp, const double* dk, const double* p, double* kp, double* J) {
   if (model == 0) {
     double fu = pp[0], fv = pp[1], cu = pp[2], cv = pp[3];
     double rz = 1.0 / p[2], rz2 = rz * rz;
     double y[2] = {p[0] * rz, p[1] * rz};
     double Jd[4];
-    distort(dist, dk, y, J ? Jd : nullptr);
+    distort<EQUI>(dist, dk, y, J ? Jd : nullptr);
     if (J) {
       J[0] = fu * Jd[0] * rz; J[1] = fu * Jd[1] * rz; J[2] = -fu * (p[0] * Jd[0] + p[1] * Jd[1]) * rz2;
       J[3] = fv * Jd[2] * rz; J[4] = fv * Jd[3] * rz; J[5] = -fv * (p[0] * Jd[2] + p[1] * Jd[3]) * rz2;
@@ -390,7 +393,7 @@ MC_HD void project(int model, int dist, const double* pp, const double* dk, cons
       Jn[2] = p[0] * q; Jn[5] = p[1] * q;
     }
     double Jd[4];
-    distort(dist, dk, y, J ? Jd : nullptr);
+    distort<EQUI>(dist, dk, y, J ? Jd : nullptr);
     if (J) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -474,13 +477,15 @@ MC_HD void distortion_jacobian(int model, int dist, const double* pp, const doub
 }
 
 // M-estimator weight, AB/src/MEstimatorPolicies.cpp:17-129
+// EXPW = false compiles the Blake-Zisserman weight (exp) out: for launches that hold no such batch
+template <bool EXPW = true>
 MC_HD double mest_weight(int kind, double a, double e2) {
   switch (kind) {
     case 1: return e2 < a * a ? 1.0 : a / sqrt(e2);
     case 2: return 1.0 / (1.0 + e2 / a);
     case 3: { double se = a + e2; return a / (se * se); }
     case 4: return e2 < a * a ? 1.0 : (a * a) / e2;
-    case 5: { double ex = exp(-e2); return ex / (ex + a); }
+    case 5: if (EXPW) { double ex = exp(-e2); return ex / (ex + a); } return 1.0;
     default: return 1.0;
   }
 }

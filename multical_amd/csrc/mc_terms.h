@@ -149,6 +149,7 @@ MC_HD void f1_common(const ReprojBatchView& b, const double* x, int obs, F1Commo
   rigid_mul(cm.X, Twp, cm.Tcp);
 }
 // One corner, first half: camera-frame point, projection (+ 2x3 Jacobian), weighted residual e[2], sw = sqrt(w) * s.
+template <bool EQUI = true, bool EXPW = true>
 MC_HD void f1_project(const ReprojBatchView& b, const double* x, const F1Common& cm, int k, bool useM, bool wantJ,
                       double* pc, double* Jc, double* e, double& sw, TermOut& out) {
   const double* pt = b.p + 3 * (size_t)k;
@@ -156,11 +157,11 @@ MC_HD void f1_project(const ReprojBatchView& b, const double* x, const F1Common&
   pc[0] += cm.Tcp.r[0]; pc[1] += cm.Tcp.r[1]; pc[2] += cm.Tcp.r[2];
   double kp[2];
   (void)x;
-  project(b.cam.model, b.cam.dist, cm.pp, cm.dk, pc, kp, wantJ ? Jc : nullptr);
+  project<EQUI>(b.cam.model, b.cam.dist, cm.pp, cm.dk, pc, kp, wantJ ? Jc : nullptr);
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
   double s = b.sinv[k];
   out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
-  out.w = mest_weight(b.mest, b.mest_a, out.chi2);
+  out.w = mest_weight<EXPW>(b.mest, b.mest_a, out.chi2);
   sw = (useM ? sqrt(out.w) : 1.0) * s;
   e[0] = sw * e0; e[1] = sw * e1;
 }
