@@ -64,24 +64,25 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     dCx = torch.zeros(api.nnz, dtype=torch.float64, device=dev)
-    drhs = torch.zeros(api.j_cols, dtype=torch.float64, device=dev)
-    dJ = torch.zeros(1, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-
+    # One exchange buffer per step: [ Cx entries shared between ranks | rhs | J ].  rhs and J are written straight into it
+    # by the entry points, the shared entries are gathered by mc_pack_shared: ONE all-reduce per Gauss-Newton iteration.
     n_shared = len(api.shared_indices()) if world > 1 else 0
-    dshared = torch.zeros(max(1, n_shared), dtype=torch.float64, device=dev)
+    xbuf = torch.zeros(n_shared + api.j_cols + 1, dtype=torch.float64, device=dev)
+    dshared, drhs, dJ = xbuf[:n_shared], xbuf[n_shared:n_shared + api.j_cols], xbuf[n_shared + api.j_cols:]
+
+    def exchange():
+        # partial Hessians: only the entries two ranks can write (window halos, global x global blocks) are summed;
+        # every other entry already sits complete on the rank that owns its time window
+        api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
+        dist.all_reduce(xbuf)
+        api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
 
     def step():
         api.evaluate_error_device(True, dJ.data_ptr(), None, stream)
         api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), stream)
         if world > 1:
-            # partial Hessians: only the entries two ranks can write (window halos, global x global blocks) are summed;
-            # every other entry already sits complete on the rank that owns its time window
-            api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
-            dist.all_reduce(dshared)
-            api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
-            dist.all_reduce(drhs)
-            dist.all_reduce(dJ)
+            exchange()
 
     def fence():
         if world > 1:
@@ -106,11 +107,7 @@ def main():
     def fused_step():
         api.evaluate_error_and_build_system_device(True, dJ.data_ptr(), None, dCx.data_ptr(), drhs.data_ptr(), stream)
         if world > 1:
-            api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
-            dist.all_reduce(dshared)
-            api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
-            dist.all_reduce(drhs)
-            dist.all_reduce(dJ)
+            exchange()
     fused_step()
     fence()
     t2 = time.perf_counter()
@@ -197,7 +194,7 @@ def main():
                            build_ms=round(build_wall_ms, 4), build_kernels_serial_ms=round(float(ms_build.sum()), 4), evaluate_ms=round(float(ms_eval.sum()), 4),
                            fused_evaluate_and_build_ms=round(dt_fused / args.steps * 1e3, 4),
                            setup_s=round(t_setup, 2), shared_values=n_shared,
-                           sharding="time windows, global pattern; RCCL all-reduce of rhs, J and the Cx entries shared between ranks" if world > 1 else "none"),
+                           sharding="time windows, global pattern; one RCCL all-reduce of [shared Cx entries | rhs | J] per step" if world > 1 else "none"),
                roofline=roofline)
 
     if args.solve and rank == 0:

@@ -220,6 +220,27 @@ def test_fused_evaluate_and_build_equals_the_two_calls(hip_small, use_mest):
     assert np.array_equal(de.cpu().numpy(), e)
 
 
+def test_contended_entry_replicas_change_nothing(small_problem, small_oracle, monkeypatch):
+    """Entries between global design variables are accumulated in replicas and folded into Cx / rhs by k_rep_reduce;
+    MC_NO_REPLICAS=1 sends them straight to Cx like every other entry.  Both must give the oracle's system."""
+    o, _ = small_oracle
+    o.evaluate_error(True)
+    Cp, Ci, Cx, rhs = o.build_system(True)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MC_NO_REPLICAS", "1")
+        g, _ = _hip(small_problem["spec"])
+        g.evaluate_error(True)
+        a, b = g.build_system(True)
+        a2, b2 = g.build_system(True)          # the replicas are cleared by every call
+        assert np.abs(a2 - a).max() <= 1e-12 * np.abs(a).max() and np.abs(b2 - b).max() <= 1e-12 * np.abs(b).max()
+        assert np.abs(a - Cx).max() <= RTOL * np.abs(Cx).max() and np.abs(b - rhs).max() <= RTOL * np.abs(rhs).max()
+        res.append((a, b))
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-12 * np.abs(Cx).max()
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-12 * np.abs(rhs).max()
+
+
 def test_time_offset_buffer_exceeded_is_reported(small_problem):
     """TransformationTimeOffsetExpressionNode throws 'Spline Coefficient Buffer Exceeded' when the time offset leaves the
     frozen buffer (BSplineExpressions.cpp:447, 503)."""
