@@ -86,6 +86,12 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+// orders a wave's own LDS traffic: its lanes wrote, now any of its lanes may read (no workgroup barrier involved)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // replica of this workgroup for the contended entries (gi <= gj compact global columns)
 __device__ __forceinline__ double* rep_entry(const DevCommon& dc, int gi, int gj) {
   return dc.rep + (size_t)(blockIdx.x & (Problem::REP_COPIES - 1)) * dc.rep_stride + (gj * (gj + 1)) / 2 + gi;
@@ -202,37 +208,38 @@ __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, c
   }
 }
 
-// evaluateError for F1: one 256-thread workgroup per IMAGE, its observations (one per visible board) one after the other,
-// thread = corner.  The per-observation record is staged in LDS (prefetched one observation ahead) and read back by
-// broadcast; the kernel streams y / p / sinv, projects and stores chi^2 (and e).
+// evaluateError for F1: one 256-thread workgroup per IMAGE, one WAVE per observation (the four waves take the image's
+// observations in turn, no workgroup barrier), lane = corner.  The per-observation record is staged in the wave's LDS slot
+// and read back by broadcast; the kernel streams y / p / sinv, projects and stores chi^2 (and e).
 __global__ __launch_bounds__(256) void k_reproj_eval(const ReprojBatchView* __restrict__ views, DevCommon dc,
                                                      const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
                                                      const F1Common* __restrict__ common, int jpart_base) {
+  constexpr int NCM = (int)(sizeof(F1Common) / 8);
+  static_assert(sizeof(F1Common) % 8 == 0, "F1Common is copied as doubles");
   __shared__ double red[4];
-  __shared__ F1Common cm;
-  const int tid = threadIdx.x;
+  __shared__ double cm_all[4][NCM];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const F1Common& cm = *reinterpret_cast<const F1Common*>(cm_all[wv]);
   const ImageRec im = images[blockIdx.x];
   double Jacc = 0.0;
-  constexpr int NCM = (int)(sizeof(F1Common) / 8);
-  static_assert(sizeof(F1Common) % 8 == 0 && NCM <= 256, "F1Common is copied as doubles, one per thread");
-  double pf_cm = 0.0;
-  if (tid < NCM) pf_cm = reinterpret_cast<const double*>(common + im.first)[tid];
-  for (int go = 0; go < im.count; ++go) {
+  for (int go = wv; go < im.count; go += 4) {
     const int gi = im.first + go;
     const GroupRec gr = groups[gi];
     const ReprojBatchView b = views[gr.batch];
-    __syncthreads();   // the previous observation is done with cm
-    if (tid < NCM) reinterpret_cast<double*>(&cm)[tid] = pf_cm;
-    __syncthreads();
-    if (go + 1 < im.count && tid < NCM) pf_cm = reinterpret_cast<const double*>(common + gi + 1)[tid];
-    if (!cm.ok) { if (tid == 0) atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); continue; }
+    wave_sync();   // the previous observation is done with the record
+    {
+      const double* src = reinterpret_cast<const double*>(common + gi);
+      for (int i = lane; i < NCM; i += 64) cm_all[wv][i] = src[i];
+    }
+    wave_sync();
+    if (!cm.ok) { if (lane == 0) atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); continue; }
     {
       // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
       const FpView f = fp_view_at(dc.fp_data + dc.fp_off[gr.fp]);
       const int shift = cm.seg - f.coef_lo;
-      if (f.rolecol[F1_ROLE_COEF] >= 0 && (shift < 0 || shift + S6 > f.nbuf)) { if (tid == 0) atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); continue; }
+      if (f.rolecol[F1_ROLE_COEF] >= 0 && (shift < 0 || shift + S6 > f.nbuf)) { if (lane == 0) atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); continue; }
     }
-    for (int k = tid; k < gr.term_count; k += 256) {
+    for (int k = lane; k < gr.term_count; k += 64) {
       const int term = gr.term_first + k;
       double pc[3], Jc[6], e[2], sw;
       TermOut out;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void k_reproj_eval(const ReprojBatchView* __re
     }
   }
   Jacc = wave_sum(Jacc);
-  if ((tid & 63) == 0) red[tid >> 6] = Jacc;
+  if (lane == 0) red[wv] = Jacc;
   __syncthreads();
   if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
@@ -254,11 +261,6 @@ __global__ __launch_bounds__(256) void k_reproj_eval(const ReprojBatchView* __re
 // cores, applies the observation's chain matrix (M = Kt^T G Kt, 20 x 20), flushes the board rows / columns itself and adds
 // the rest into the image's accumulator in LDS; after the single barrier the whole workgroup flushes the image-level part.
 // (The previous shape -- a workgroup per observation, ~9 barriers per observation with half the lanes idle -- was 10 % slower.)
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 #ifndef MC_RB_OCC
 #define MC_RB_OCC 3
 #endif
@@ -609,7 +611,11 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
   if ((tid & 63) == 0) red[tid >> 6] = Jacc;
   __syncthreads();
   MC_MARK(pslot + 1);   // waiting for the other waves
-  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (tid == 0) {
+    double Js = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) Js += red[w];   // evaluate launches use fewer waves per chunk
+    dc.Jpart[jpart_base + blockIdx.x] = Js;
+  }
   if (!build) return;
   // Terms are time sorted and share one time offset, so beta0 is non-decreasing over the chunk and the terms of
   // segment s are exactly the run [rlo[s], rhi[s]) (a failed term inside a run has an all-zero row).  A violation
@@ -1751,15 +1757,15 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
         break;
       case LAUNCH_IMU:
         if (build) hipLaunchKernelGGL((k_stream<ImuBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
-        else hipLaunchKernelGGL((k_stream<ImuBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else hipLaunchKernelGGL((k_stream<ImuBatchView, false>), dim3(L.n_items), dim3(std::min(256, (L.dims.maxT + 63) & ~63)), 0, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_LIDAR:
         if (build) hipLaunchKernelGGL((k_stream<LidarBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
-        else hipLaunchKernelGGL((k_stream<LidarBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else hipLaunchKernelGGL((k_stream<LidarBatchView, false>), dim3(L.n_items), dim3(std::min(256, (L.dims.maxT + 63) & ~63)), 0, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_IMU_SM:
         if (build) hipLaunchKernelGGL((k_stream<ImuSmBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
-        else hipLaunchKernelGGL((k_stream<ImuSmBatchView, false>), dim3(L.n_items), dim3(256), 0, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else hipLaunchKernelGGL((k_stream<ImuSmBatchView, false>), dim3(L.n_items), dim3(std::min(256, (L.dims.maxT + 63) & ~63)), 0, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_GYRO_PRIOR:
         if (build) hipLaunchKernelGGL((k_small<GyroPriorBatchView, true>), dim3(L.n_items), dim3(256), 0, st, L.gviews.p, dc, L.groups.p, L.jpart_base);
