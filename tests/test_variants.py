@@ -11,6 +11,8 @@ ABI against the oracle (1e-9).  Variants of the small Multical problem:
   scale_misalignment    every IMU modelled as ScaledMisalignedImu (--imu-models scale-misalignment): MatrixBasic design
                         variables M_accel / M_gyro / M_accel_gyro and the gyroscope axis rotation q_gyro_i
   size_effect           ScaledMisalignedSizeEffectImu: per-axis accelerometer lever arms on top of the above
+  empty_batches         every sensor stream followed by an EMPTY batch of the same kind (a sensor without usable data:
+                        no observations / no samples / no points); they add no rows, no blocks and no work items
 """
 import copy
 
@@ -21,7 +23,7 @@ from multical_amd import spec as S
 
 RTOL = 1e-9
 VARIANTS = ["no_time_calibration", "pose_fixed", "static_bias_point_g", "all_mestimators", "unsorted_streams", "ragged",
-            "scale_misalignment", "size_effect"]
+            "scale_misalignment", "size_effect", "empty_batches"]
 
 
 def make_variant(spec, name):
@@ -81,6 +83,25 @@ def make_variant(spec, name):
             for f in ("t", "dir", "range", "sinv"):
                 d[f] = d[f][:1]
             d["dv_q_pw"], d["dv_t_pw"] = d["dv_q_pw"][:1], d["dv_t_pw"][:1]
+    elif name == "empty_batches":
+        for i, k, d in list(sp.batch_ops()):
+            if k in ("lidar", "accel", "gyro"):
+                e = copy.deepcopy(d)
+                for f in ("t", "dir", "range", "sinv", "meas"):
+                    if f in e:
+                        e[f] = e[f][:0]
+                if k == "lidar":
+                    e["dv_q_pw"], e["dv_t_pw"] = [], []
+                sp.ops.append((k, e))
+            elif k == "reproj":
+                e = copy.deepcopy(d)
+                e["obs_first"], e["obs_time"] = np.zeros(1, np.int32), e["obs_time"][:0]
+                for f in ("y", "p", "sinv"):
+                    e[f] = e[f][:0]
+                for f in list(e):
+                    if f.startswith("obs_dv"):
+                        e[f] = []
+                sp.ops.append((k, e))
     elif name in ("scale_misalignment", "size_effect"):
         # sensors_and_targets.py:1428-1447, 1583-1606: the extra design variables of the two models, at values away from
         # their identity / zero initial guesses so that every chain carries signal
