@@ -44,9 +44,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # Rehearsal aid for a one-GPU box: MC_BENCH_REHEARSE=1 puts every rank on cuda:0 and exchanges through gloo, so the
+    # N > 1 code path (shards, exchange buffer, timing) can be run where RCCL has no second device to talk to.
+    rehearse = world > 1 and os.environ.get("MC_BENCH_REHEARSE") == "1"
+    if world > 1:
+        # N > 1: every context of this process (the unsharded one that synthesises the measurements included) launches on
+        # the caller's stream; the side streams are worth 2 % and share the process's 4 hardware queues with RCCL's
+        os.environ.setdefault("MC_SERIAL_LAUNCH", "1")
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    verbose = os.environ.get("MC_BENCH_VERBOSE") == "1"
+
+    def note(msg):
+        if verbose:
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
     base = synth.baseline_config(args.config)
     per_gpu = args.duration if args.duration is not None else base.duration
@@ -61,6 +79,7 @@ def main():
     spec.emit(api)
     api.finalize()
     t_setup = time.time() - t0
+    note("set-up done in %.1f s, %d terms, nnz %d" % (t_setup, api.n_terms, api.nnz))
 
     dev = torch.device("cuda", local_rank)
     dCx = torch.zeros(api.nnz, dtype=torch.float64, device=dev)
@@ -75,7 +94,12 @@ def main():
         # partial Hessians: only the entries two ranks can write (window halos, global x global blocks) are summed;
         # every other entry already sits complete on the rank that owns its time window
         api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
-        dist.all_reduce(xbuf)
+        if rehearse:
+            h = xbuf.cpu()            # gloo on host memory; its device-tensor staging hung with two ranks on one GPU
+            dist.all_reduce(h)
+            xbuf.copy_(h)
+        else:
+            dist.all_reduce(xbuf)
         api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
 
     def step():
@@ -91,14 +115,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    note("warm-up launched")
     fence()
+    note("warm-up done")
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t1
+    note("timed steps done")
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     api.check_status()
@@ -116,7 +143,7 @@ def main():
     fence()
     dt_fused = time.perf_counter() - t2
     if world > 1:
-        tt = torch.tensor([dt_fused], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt_fused], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_fused = tt.item()
     api.check_status()

@@ -1376,6 +1376,10 @@ struct mc_context {
     if (side_state == 0) {
       const char* s = getenv("MC_SERIAL_LAUNCH");
       if (s && s[0] == '1') { side_state = -1; return false; }
+      // With shards the step also holds a collective whose library brings streams of its own, and the process has
+      // GPU_MAX_HW_QUEUES = 4 hardware queues.  The overlap is worth 2 % and the N > 1 runs cannot be rehearsed with RCCL on a
+      // one-GPU box, so sharded contexts launch serially unless MC_SERIAL_LAUNCH=0 asks for the side streams.
+      if (P.world > 1 && !(s && s[0] == '0')) { side_state = -1; return false; }
       for (int i = 0; i < N_SIDE; ++i) {
         HIP_CHECK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
