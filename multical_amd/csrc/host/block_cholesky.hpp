@@ -117,28 +117,17 @@ class BlockSparseCholesky {
       for (int k = head[j], knext; k != -1; k = knext) {
         knext = next[k];
         const long long p0 = pos[k], pe = colptr_[k + 1];
-        const int dk = dim_[k], mk = m_[k], r0 = rowoff_[p0], t = mk - r0;
+        const int dk = dim_[k], mk = m_[k], r0 = rowoff_[p0];
         const double* T = Lx_.data() + valptr_[k] + r0;      // rows of block column k from block row j downwards
-        // tmp (t x dj) = T (t x dk) * T[0:dj, :]^T
-        for (int cj = 0; cj < dj; ++cj) {
-          double* o = tmp.data() + (size_t)cj * t;
-          {
-            const double b = T[cj];
-            for (int r = 0; r < t; ++r) o[r] = T[r] * b;
-          }
-          for (int ck = 1; ck < dk; ++ck) {
-            const double* a = T + (size_t)ck * mk;
-            const double b = a[cj];
-            for (int r = 0; r < t; ++r) o[r] += a[r] * b;
-          }
-        }
-        for (long long q = p0; q < pe; ++q) {
-          const int rb = rowblk_[q], d = dim_[rb], src = rowoff_[q] - r0, dst = where[rb];
-          for (int cj = 0; cj < dj; ++cj) {
-            double* pd = P + dst + (size_t)cj * mj;
-            const double* ps = tmp.data() + src + (size_t)cj * t;
-            for (int r = 0; r < d; ++r) pd[r] -= ps[r];
-          }
+        // P[rows of k below j, :] -= T * T[0:dj, :]^T, by runs of row blocks that are contiguous in both panels (in the
+        // banded part a descendant's rows map onto the target's rows as two or three runs: band, border)
+        for (long long q = p0; q < pe;) {
+          const int src = rowoff_[q] - r0, dst = where[rowblk_[q]];
+          int len = dim_[rowblk_[q]];
+          long long q2 = q + 1;
+          while (q2 < pe && where[rowblk_[q2]] == dst + len) { len += dim_[rowblk_[q2]]; ++q2; }
+          panelUpdate(T, mk, src, len, dk, dj, P + dst, mj, tmp.data());
+          q = q2;
         }
         pos[k] = p0 + 1;
         if (p0 + 1 < pe) { int r = rowblk_[p0 + 1]; next[k] = head[r]; head[r] = k; }
@@ -253,6 +242,66 @@ class BlockSparseCholesky {
   bool analyzed() const { return analyzed_; }
 
  private:
+  // P (len x DJ, leading dimension ldp) -= T[src : src + len, :] (len x DK, leading dimension ld) * T[0:DJ, :]^T.  This
+  // update is where the factorisation spends its flops; with the block dimensions known at compile time the DJ x DK
+  // coefficients and the DK values of a row stay in registers and the loop over the rows vectorises (DK loads, DJ
+  // load-subtract-stores per DK * DJ multiply-adds).
+  template <int DK, int DJ>
+  static void panelUpdateFixed(const double* __restrict__ T, int ld, int src, int len, double* __restrict__ P, int ldp) {
+    double B[DJ][DK];
+    for (int cj = 0; cj < DJ; ++cj)
+      for (int ck = 0; ck < DK; ++ck) B[cj][ck] = T[cj + (size_t)ck * ld];
+    const double* __restrict__ S = T + src;
+#pragma GCC ivdep
+    for (int r = 0; r < len; ++r) {
+      double a[DK];
+      for (int ck = 0; ck < DK; ++ck) a[ck] = S[r + (size_t)ck * ld];
+      for (int cj = 0; cj < DJ; ++cj) {
+        double s = a[0] * B[cj][0];
+        for (int ck = 1; ck < DK; ++ck) s += a[ck] * B[cj][ck];
+        P[r + (size_t)cj * ldp] -= s;
+      }
+    }
+  }
+  template <int DK>
+  static bool panelUpdateDj(const double* T, int ld, int src, int len, int dj, double* P, int ldp) {
+    switch (dj) {
+      case 1: panelUpdateFixed<DK, 1>(T, ld, src, len, P, ldp); return true;
+      case 2: panelUpdateFixed<DK, 2>(T, ld, src, len, P, ldp); return true;
+      case 3: panelUpdateFixed<DK, 3>(T, ld, src, len, P, ldp); return true;
+      case 4: panelUpdateFixed<DK, 4>(T, ld, src, len, P, ldp); return true;
+      case 5: panelUpdateFixed<DK, 5>(T, ld, src, len, P, ldp); return true;
+      case 6: panelUpdateFixed<DK, 6>(T, ld, src, len, P, ldp); return true;
+      default: return false;
+    }
+  }
+  static void panelUpdate(const double* T, int ld, int src, int len, int dk, int dj, double* P, int ldp, double* tmp) {
+    bool done = false;
+    switch (dk) {
+      case 1: done = panelUpdateDj<1>(T, ld, src, len, dj, P, ldp); break;
+      case 2: done = panelUpdateDj<2>(T, ld, src, len, dj, P, ldp); break;
+      case 3: done = panelUpdateDj<3>(T, ld, src, len, dj, P, ldp); break;
+      case 4: done = panelUpdateDj<4>(T, ld, src, len, dj, P, ldp); break;
+      case 5: done = panelUpdateDj<5>(T, ld, src, len, dj, P, ldp); break;
+      case 6: done = panelUpdateDj<6>(T, ld, src, len, dj, P, ldp); break;
+      default: break;
+    }
+    if (done) return;
+    for (int cj = 0; cj < dj; ++cj) {     // any other block dimension: column by column through tmp
+      {
+        const double b = T[cj];
+        for (int r = 0; r < len; ++r) tmp[r] = T[src + r] * b;
+      }
+      for (int ck = 1; ck < dk; ++ck) {
+        const double* a = T + (size_t)ck * ld;
+        const double b = a[cj];
+        for (int r = 0; r < len; ++r) tmp[r] += a[src + r] * b;
+      }
+      double* pd = P + (size_t)cj * ldp;
+      for (int r = 0; r < len; ++r) pd[r] -= tmp[r];
+    }
+  }
+
   // Minimum (weighted external) degree on the quotient graph: eliminated blocks become elements whose member lists stand
   // for the cliques they created; degrees of the members of a new element are recomputed exactly.
   void minimumDegree(const std::vector<std::vector<int>>& adj, const std::vector<int>& w) {
