@@ -173,29 +173,38 @@ class BlockSparseCholesky {
         const double v = yj[c];
         for (int r = c + 1; r < dj; ++r) yj[r] -= pc[r] * v;
       }
-      for (long long q = colptr_[j] + 1; q < colptr_[j + 1]; ++q) {
-        const int rb = rowblk_[q], d = dim_[rb], ro = rowoff_[q];
-        double* yr = y.data() + pbase_[rb];
+      // rows below the diagonal block, by runs of row blocks that are neighbours in the permuted order (contiguous in y)
+      for (long long q = colptr_[j] + 1; q < colptr_[j + 1];) {
+        const int ro = rowoff_[q], y0 = pbase_[rowblk_[q]];
+        int len = dim_[rowblk_[q]];
+        long long q2 = q + 1;
+        while (q2 < colptr_[j + 1] && pbase_[rowblk_[q2]] == y0 + len) { len += dim_[rowblk_[q2]]; ++q2; }
+        double* yr = y.data() + y0;
         for (int c = 0; c < dj; ++c) {
           const double* pc = P + ro + (size_t)c * mj;
           const double v = yj[c];
-          for (int r = 0; r < d; ++r) yr[r] -= pc[r] * v;
+          for (int r = 0; r < len; ++r) yr[r] -= pc[r] * v;
         }
+        q = q2;
       }
     }
     for (int j = nb_ - 1; j >= 0; --j) {         // L^T x' = y'
       const int dj = dim_[j], mj = m_[j];
       const double* P = Lx_.data() + valptr_[j];
       double* yj = y.data() + pbase_[j];
-      for (long long q = colptr_[j] + 1; q < colptr_[j + 1]; ++q) {
-        const int rb = rowblk_[q], d = dim_[rb], ro = rowoff_[q];
-        const double* yr = y.data() + pbase_[rb];
+      for (long long q = colptr_[j] + 1; q < colptr_[j + 1];) {
+        const int ro = rowoff_[q], y0 = pbase_[rowblk_[q]];
+        int len = dim_[rowblk_[q]];
+        long long q2 = q + 1;
+        while (q2 < colptr_[j + 1] && pbase_[rowblk_[q2]] == y0 + len) { len += dim_[rowblk_[q2]]; ++q2; }
+        const double* yr = y.data() + y0;
         for (int c = 0; c < dj; ++c) {
           const double* pc = P + ro + (size_t)c * mj;
           double s = 0.0;
-          for (int r = 0; r < d; ++r) s += pc[r] * yr[r];
+          for (int r = 0; r < len; ++r) s += pc[r] * yr[r];
           yj[c] -= s;
         }
+        q = q2;
       }
       for (int c = dj - 1; c >= 0; --c) {
         const double* pc = P + (size_t)c * mj;
