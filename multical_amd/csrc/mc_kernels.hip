@@ -2,12 +2,19 @@
 // BlockCholeskyLinearSystemSolver::buildSystem (aslam_backend/src/LinearSystemSolver.cpp:12-92,
 // BlockCholeskyLinearSystemSolver.cpp:58-72) plus the state update, and the C ABI of include/multical_hip.h.
 //
-// Execution shape (DESIGN.md has the numbers): one 64-lane wavefront per *group* of error terms that write
-// the same Hessian blocks.  Lanes evaluate one term each (closed forms of mc_terms.h, all in registers),
-// park the weighted Jacobian rows in an LDS tile whose columns follow the group's sorted block order, reduce
-// J^T J for the whole group out of LDS, and only then touch HBM: one fp64 atomic per distinct Hessian entry
-// of the group, lanes walking down a CCS column so the adds of a wave instruction are contiguous.  The value
-// array the atomics land in *is* the fillCCS(upper) array -- there is no block matrix to convert afterwards.
+// Execution shape (DESIGN.md section 4 has the numbers).  One launch per term family and pass:
+//   F1 reprojection   k_obs_common (lane per observation: what its corners share, and the 6 x 19 matrix of the chain rule
+//                     below the camera) -> k_reproj_eval / k_reproj_build: workgroup per image, wave per observation,
+//                     lane per corner; build reduces the 7 x 7 Gram of [a, a x p_c | residual] on the fp64 matrix cores
+//                     and expands it once per observation
+//   F2 static views   k_static_common -> k_static: workgroup per run of observations of one camera
+//   F3/F4/F5 streams  k_stream: workgroup per chunk of consecutive time-sorted terms; rows in an LDS tile, every Hessian
+//                     entry of the chunk's window gathered out of LDS by one thread
+//   F6, F7            k_small, k_motion
+// Each distinct Hessian entry of a work item costs ONE fp64 atomic, lanes walking down a CCS column so the adds of a wave
+// instruction are contiguous; entries between global design variables (written by every work item) go to replicas that
+// k_rep_reduce folds in.  The value array the atomics land in *is* the fillCCS(upper) array -- there is no block matrix
+// to convert afterwards.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <memory>
