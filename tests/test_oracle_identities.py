@@ -11,10 +11,11 @@ import pytest
 
 def _fd_check(o, terms, tol):
     worst = 0.0
+    nt = 4   # LinearSystemSolver::evaluateError's thread fan-out (LinearSystemSolver.cpp:50-78); every call re-walks all terms
     for term in terms:
         # expression nodes cache operands during evaluateError (e.g. EuclideanExpressionNodeMultiply::_C_lhs), so the
         # Jacobians are only valid right after an evaluation at the same state
-        o.evaluate_error(False)
+        o.evaluate_error(False, False, nt)
         Ja, _ = o.term_weighted_jacobian(int(term), False)
         cols = np.nonzero(np.abs(Ja).sum(0))[0]
         for c in cols:
@@ -24,7 +25,7 @@ def _fd_check(o, terms, tol):
                 dx = np.zeros(o.j_cols)
                 dx[c] = s
                 o.apply_update(dx)
-                o.evaluate_error(False)
+                o.evaluate_error(False, False, nt)
                 e.append(o.term_weighted_jacobian(int(term), False)[1])
                 o.revert_update()
             fd = (e[0] - e[1]) / (2 * h)
@@ -63,8 +64,10 @@ def test_assembled_system_equals_dense_normal_equations(small_oracle, small_prob
         else:
             for t in range(base, base + cnt):
                 Jt, et = o.term_weighted_jacobian(t, True)
-                H += Jt.T @ Jt
-                g -= Jt.T @ et
+                cols = np.nonzero(np.abs(Jt).sum(0))[0]     # a term touches ~60-90 of the columns
+                Jc = Jt[:, cols]
+                H[np.ix_(cols, cols)] += Jc.T @ Jc
+                g[cols] -= Jc.T @ et
         base += cnt
     import scipy.sparse as sp
     U = sp.csc_matrix((Cx, Ci, Cp), shape=(n, n)).toarray()
