@@ -210,7 +210,7 @@ def test_imu_model_oracle_jacobians_match_finite_differences(variants, name):
             terms += [base + 1, base + n // 2]
         base += n
     assert terms
-    _fd_check(o, terms, 1e-6)
+    _fd_check(o, terms, 1e-6, nt=4)
 
 
 @pytest.mark.gpu
