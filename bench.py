@@ -263,18 +263,20 @@ def cpu_baseline(args, synth):
     o = OracleApi()
     spec.emit(o)
     o.finalize()
-    cores = min(16, max(1, (os.cpu_count() or 2) - 1))
-    o.evaluate_error(True, False, cores)
+    # evaluateError on ONE thread: the oracle's terms share expression nodes whose cached operands are heap matrices, so the
+    # reference's thread fan-out (LinearSystemSolver.cpp:50-78) is not safe on it; buildSystem, which dominates, is serial
+    # in the reference itself
+    o.evaluate_error(True, False, 1)
     t = time.perf_counter()
-    o.evaluate_error(True, False, cores)
+    o.evaluate_error(True, False, 1)
     t_eval = time.perf_counter() - t
     t = time.perf_counter()
     o.build_only(True)
     t_build = time.perf_counter() - t
-    return dict(value=o.n_terms / (t_eval + t_build), unit="error-terms/s", cores=cores if t_eval > t_build else 1, kind="port",
+    return dict(value=o.n_terms / (t_eval + t_build), unit="error-terms/s", cores=1, kind="port",
                 sample="first %.1f s of the same workload (%d error terms): buildSystem serial on 1 core as in the reference "
-                       "(%.3f s), evaluateError on %d threads (%.3f s)" % (args.cpu_sample_seconds, o.n_terms, t_build, cores, t_eval),
-                build_terms_per_s=o.n_terms / t_build, evaluate_threads=cores)
+                       "(%.3f s), evaluateError on 1 thread (%.3f s)" % (args.cpu_sample_seconds, o.n_terms, t_build, t_eval),
+                build_terms_per_s=o.n_terms / t_build, evaluate_threads=1)
 
 
 if __name__ == "__main__":

@@ -218,6 +218,7 @@ __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, c
 // evaluateError for F1: one 256-thread workgroup per IMAGE, one WAVE per observation (the four waves take the image's
 // observations in turn, no workgroup barrier), lane = corner.  The per-observation record is staged in the wave's LDS slot
 // and read back by broadcast; the kernel streams y / p / sinv, projects and stores chi^2 (and e).
+template <bool EQUI, bool EXPW>
 __global__ __launch_bounds__(256) void k_reproj_eval(const ReprojBatchView* __restrict__ views, DevCommon dc,
                                                      const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
                                                      const F1Common* __restrict__ common, int jpart_base) {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void k_reproj_eval(const ReprojBatchView* __re
       const int term = gr.term_first + k;
       double pc[3], Jc[6], e[2], sw;
       TermOut out;
-      f1_project(b, dc.x, cm, term, dc.useM != 0, false, pc, Jc, e, sw, out);
+      f1_project<EQUI, EXPW>(b, dc.x, cm, term, dc.useM != 0, false, pc, Jc, e, sw, out);
       Jacc += out.w * out.chi2;
       dc.chi2[b.term_base_global + term] = out.chi2;
       if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void k_reproj_eval(const ReprojBatchView* __re
 #ifndef MC_RB_OCC
 #define MC_RB_OCC 3
 #endif
-// EQUI / EXPW: whether any camera of the launch has the equidistant distortion (atan) / any batch the Blake-Zisserman
+// EQUI / EXPW (both F1 kernels): whether any camera of the launch has the equidistant distortion (atan) / any batch the Blake-Zisserman
 // weight (exp).  Without them the kernel fits its register budget; with them the compiler parks their polynomial
 // constants in scratch (188 bytes per lane, written by every thread: 460 MB of HBM writes per launch on configs[3]).
 template <bool EQUI, bool EXPW>
@@ -1759,7 +1760,11 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
                                   : (L.reproj_expw ? k_reproj_build<false, true> : k_reproj_build<false, false>);
           hipLaunchKernelGGL(kb, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.chain.p, L.jpart_base);
         }
-        else hipLaunchKernelGGL(k_reproj_eval, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
+        else {
+          auto ke = L.reproj_equi ? (L.reproj_expw ? k_reproj_eval<true, true> : k_reproj_eval<true, false>)
+                                  : (L.reproj_expw ? k_reproj_eval<false, true> : k_reproj_eval<false, false>);
+          hipLaunchKernelGGL(ke, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.jpart_base);
+        }
         break;
       case LAUNCH_STATIC:
         hipLaunchKernelGGL(k_static_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.sviews.p, x.p, L.groups.p, L.n_items, L.common2.p);

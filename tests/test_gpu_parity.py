@@ -277,7 +277,7 @@ def test_levenberg_marquardt_matches_oracle():
     opt.linearSolver = B.HipBlockCholeskyLinearSystemSolver(g)
     opt.trustRegionPolicy = B.LevenbergMarquardtTrustRegionPolicy(10.0)
     srv = B.Optimizer2(opt).optimize()
-    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 4)
+    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 1)
     assert srv.iterations == ro["iterations"] and srv.failedIterations == ro["failedIterations"]
     assert abs(srv.JFinal - ro["JFinal"]) <= 1e-7 * ro["JFinal"]
     assert srv.JFinal < 0.1 * srv.JStart
@@ -328,7 +328,7 @@ def test_cpp_optimizer2_matches_oracle_and_python_mirror():
     iters = 6
     r = g.optimize(maxIterations=iters, convergenceDeltaX=1e-5, convergenceJDescentRatioThreshold=1e-6,
                    levenbergMarquardtLambdaInit=10.0)
-    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 4)
+    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 1)
     assert r["iterations"] == ro["iterations"] and r["failedIterations"] == ro["failedIterations"]
     assert abs(r["JStart"] - ro["JStart"]) <= 1e-9 * ro["JStart"]
     assert abs(r["JFinal"] - ro["JFinal"]) <= 1e-7 * ro["JFinal"]

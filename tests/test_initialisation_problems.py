@@ -174,7 +174,7 @@ def test_gpu_levenberg_marquardt_matches_oracle(name):
     opt.linearSolver = HipBlockCholeskyLinearSystemSolver(g)
     opt.trustRegionPolicy = LevenbergMarquardtTrustRegionPolicy(10.0)
     rv = Optimizer2(opt).optimize()
-    ro = o.optimize(iters, 10.0, 1e-4, 1e-5, 2)
+    ro = o.optimize(iters, 10.0, 1e-4, 1e-5, 1)
     assert rv.iterations == ro["iterations"] and rv.failedIterations == ro["failedIterations"]
     assert abs(rv.JFinal - ro["JFinal"]) <= 1e-7 * abs(ro["JFinal"])
     assert rv.JFinal < 0.1 * rv.JStart

@@ -113,7 +113,7 @@ def test_static_gpu_levenberg_marquardt_matches_oracle():
     opt.linearSolver = HipBlockCholeskyLinearSystemSolver(g)
     opt.trustRegionPolicy = LevenbergMarquardtTrustRegionPolicy(10.0)
     rv = Optimizer2(opt).optimize()
-    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 4)
+    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 1)
     assert rv.iterations == ro["iterations"] and rv.failedIterations == ro["failedIterations"]
     assert abs(rv.JFinal - ro["JFinal"]) <= 1e-7 * abs(ro["JFinal"])
     assert rv.JFinal < 0.5 * rv.JStart

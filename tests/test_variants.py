@@ -210,7 +210,7 @@ def test_imu_model_oracle_jacobians_match_finite_differences(variants, name):
             terms += [base + 1, base + n // 2]
         base += n
     assert terms
-    _fd_check(o, terms, 1e-6, nt=4)
+    _fd_check(o, terms, 1e-6)
 
 
 @pytest.mark.gpu
@@ -307,7 +307,7 @@ def test_levenberg_marquardt_with_imu_models_matches_oracle(small_problem, model
     o.finalize()
     iters = 5
     r = g.optimize(maxIterations=iters, convergenceDeltaX=1e-5, convergenceJDescentRatioThreshold=1e-6, levenbergMarquardtLambdaInit=10.0)
-    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 4)
+    ro = o.optimize(iters, 10.0, 1e-5, 1e-6, 1)
     assert (r["iterations"], r["failedIterations"]) == (ro["iterations"], ro["failedIterations"])
     assert abs(r["JFinal"] - ro["JFinal"]) <= 1e-7 * ro["JFinal"]
     worst, n_matrix = 0.0, 0
