@@ -182,6 +182,17 @@ int mc_build_system_device(mc_context* ctx, int use_mestimator, double* d_Cx, do
  * launches.  Results are those of the two calls above made one after the other.  d_e may be NULL. */
 int mc_evaluate_error_and_build_system_device(mc_context* ctx, int use_mestimator, double* d_J, double* d_e, double* d_Cx,
                                               double* d_rhs, void* stream);
+/* Allocation-free variant of mc_build_system_device.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * kernels, same results and same arguments as mc_build_system_device, but the scratch the build needs (the 16 replicas of
+ * the contended global x global Hessian / rhs entries) lives in a file-scope __device__ array of the library (4.05 MiB,
+ * held by every GPU the library runs on until the process ends) whose address is looked up once per device in mc_create,
+ * every launch stays on `stream` (no side streams, no events are created), and the call makes no hipMalloc / hipFree /
+ * allocating library call.  Limit: at most 256 scalar columns of global (non-spline) design variables; more is rejected
+ * with -1 and a message (problems with more than 512 such columns use no replicas and are accepted).  All contexts of a
+ * process on one GPU share that GPU's array and the call clears what it uses: calls that overlap in time on one GPU
+ * (different streams or threads) race on it -- serialise them. */
+int mc_build_system_device_noalloc(mc_context* ctx, int use_mestimator, double* d_Cx, double* d_rhs, void* stream);
 /* ---- second backend: J^T for SparseCholeskyLinearSystemSolver -------------------------------------------------
  * SparseCholeskyLinearSystemSolver::initMatrixStructureImplementation / buildSystem
  * (aslam_backend/src/SparseCholeskyLinearSystemSolver.cpp:15-45) keep the Jacobian itself: J^T (j_cols x j_rows) in

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mc_build_system": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
     "mc_evaluate_error_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mc_build_system_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mc_build_system_device_noalloc": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mc_evaluate_error_and_build_system_device": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mc_get_term_chi2": (C.c_int, [_ctx, _dp]),
     "mc_apply_update": (C.c_int, [_ctx, _dp]),

@@ -222,6 +222,10 @@ class HipApi(object):
     def build_system_device(self, use_mest, d_Cx, d_rhs, stream):
         self._chk(self.lib.mc_build_system_device(self.ctx, int(use_mest), d_Cx, d_rhs, stream))
 
+    def build_system_device_noalloc(self, use_mest, d_Cx, d_rhs, stream):
+        """mc_build_system_device with its scratch in the library's static device array: makes no allocation."""
+        self._chk(self.lib.mc_build_system_device_noalloc(self.ctx, int(use_mest), d_Cx, d_rhs, stream))
+
     def term_chi2(self):
         out = np.empty(self.n_terms)
         self._chk(self.lib.mc_get_term_chi2(self.ctx, _dp(out)))

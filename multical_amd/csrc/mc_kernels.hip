@@ -1350,6 +1350,29 @@ struct LaunchUnit {
 
 using namespace mc;
 
+// ---------------------------------------------------------------------------------------------
+// Scratch of the allocation-free entry point (mc_build_system_device_noalloc): the replicas of the contended
+// global x global entries live in this file-scope device array instead of a buffer the context allocated.  Every GPU the
+// library runs on holds its own copy (4.05 MiB) until the process ends.  In host code the array's NAME is only a stand-in:
+// the device address is looked up once per device (mc_create, with that device current) and kept in g_scratch_ptr[];
+// host code below uses that pointer, never the name.
+enum { NOALLOC_MAX_COLS = 256,
+       NOALLOC_SCRATCH_DOUBLES = Problem::REP_COPIES * (NOALLOC_MAX_COLS * (NOALLOC_MAX_COLS + 1) / 2 + NOALLOC_MAX_COLS) };
+static __device__ __align__(256) double scratch[NOALLOC_SCRATCH_DOUBLES];
+enum { MAX_DEVICES = 64 };
+static double* g_scratch_ptr[MAX_DEVICES];   // per device, set by scratchOfDevice()
+// device must be the current device
+static double* scratchOfDevice(int device) {
+  if (device < 0 || device >= MAX_DEVICES) throw std::runtime_error("device index beyond the scratch table");
+  if (!g_scratch_ptr[device]) {
+    double* p = nullptr;
+    HIP_CHECK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    if (!p) throw std::runtime_error("hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[device] = p;
+  }
+  return g_scratch_ptr[device];
+}
+
 struct mc_context {
   Problem P;
   std::string err;
@@ -1399,8 +1422,10 @@ struct mc_context {
   }
 
   void uploadStructure();
+  // rep_buf: replica buffer to use instead of the context's own (the allocation-free entry point passes the per-device
+  // scratch array); serial: keep every launch on the caller's stream (no side streams are created or used)
   void launchAll(int build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
-                 std::vector<hipEvent_t>* ev = nullptr);
+                 std::vector<hipEvent_t>* ev = nullptr, double* rep_buf = nullptr, bool serial = false);
   void launchJt(int useM, double* dValues, hipStream_t st);
 };
 
@@ -1715,7 +1740,7 @@ void mc_context::uploadStructure() {
 }
 
 void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
-                           std::vector<hipEvent_t>* ev) {
+                           std::vector<hipEvent_t>* ev, double* rep_buf, bool serial) {
   DevCommon dc;
   dc.x = x.p; dc.fp_data = fp_data.p; dc.fp_off = fp_off.p; dc.col_h = col_h.p;
   dc.ofp_data = ofp_data.p; dc.ofp_off = ofp_off.p;
@@ -1726,20 +1751,21 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   dc.phase = phase_on ? phase.p : nullptr;
   const bool use_rep = build && rep_stride > 0;
   dc.gcb = use_rep ? gcb.p : nullptr;
-  dc.rep = use_rep ? rep.p : nullptr;
-  dc.rep_rhs = use_rep ? rep.p + (size_t)Problem::REP_COPIES * rep_stride : nullptr;
+  double* const rep_base = rep_buf ? rep_buf : rep.p;
+  dc.rep = use_rep ? rep_base : nullptr;
+  dc.rep_rhs = use_rep ? rep_base + (size_t)Problem::REP_COPIES * rep_stride : nullptr;
   dc.rep_stride = rep_stride; dc.rep_cols = P.rep_cols;
   if (build) {
     HIP_CHECK(hipMemsetAsync(dCx, 0, sizeof(double) * P.nnz, st));
     HIP_CHECK(hipMemsetAsync(dRhs, 0, sizeof(double) * P.j_cols, st));
-    if (use_rep) HIP_CHECK(hipMemsetAsync(rep.p, 0, sizeof(double) * (size_t)Problem::REP_COPIES * (rep_stride + P.rep_cols), st));
+    if (use_rep) HIP_CHECK(hipMemsetAsync(rep_base, 0, sizeof(double) * (size_t)Problem::REP_COPIES * (rep_stride + P.rep_cols), st));
   }
   if (dE && P.world > 1) HIP_CHECK(hipMemsetAsync(dE, 0, sizeof(double) * P.j_rows, st));
   // per-launch timing (ev) needs the launches back to back on one stream
   static const int side_of[N_LAUNCH] = {-1, -1, 0, 1, 2, 0, -1, -1};   // reprojection kernels stay on the caller's stream
   const hipStream_t caller = st;
   bool used[N_SIDE] = {false, false, false};
-  const bool fork = !ev && sideStreams();
+  const bool fork = !ev && !serial && sideStreams();
   if (fork) HIP_CHECK(hipEventRecord(ev_fork, caller));
   for (int l = 0; l < N_LAUNCH; ++l) {
     LaunchUnit& L = lu[l];
@@ -1879,6 +1905,7 @@ mc_context* mc_create(int device) {
     if (device < 0) HIP_CHECK(hipGetDevice(&c->device));
     else { if (device >= n) throw std::runtime_error("device index out of range"); c->device = device; }
     HIP_CHECK(hipSetDevice(c->device));
+    (void)scratchOfDevice(c->device);   // once per device: address of this GPU's copy of the scratch array
     return c.release();
   } catch (const std::exception& ex) { g_create_error = ex.what(); return nullptr; }
 }
@@ -2045,6 +2072,20 @@ int mc_evaluate_error_and_build_system_device(mc_context* ctx, int use_mestimato
   if (!d_J || !d_Cx || !d_rhs) throw std::invalid_argument("d_J, d_Cx and d_rhs are required");
   HIP_CHECK(hipSetDevice(ctx->device));
   ctx->launchAll(true, use_mestimator, d_Cx, d_rhs, d_J, d_e, (hipStream_t)stream);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_build_system_device_noalloc(mc_context* ctx, int use_mestimator, double* d_Cx, double* d_rhs, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  if (!d_Cx || !d_rhs) throw std::invalid_argument("d_Cx and d_rhs are required");
+  if (ctx->rep_stride > 0 && ctx->P.rep_cols > NOALLOC_MAX_COLS)
+    throw std::length_error("mc_build_system_device_noalloc: the problem has " + std::to_string(ctx->P.rep_cols) +
+                            " scalar columns of global design variables; the static scratch array holds at most " +
+                            std::to_string((int)NOALLOC_MAX_COLS) + " (use mc_build_system_device)");
+  HIP_CHECK(hipSetDevice(ctx->device));
+  // no hipMalloc / hipFree / stream or event creation from here on: the replicas live in this device's scratch array
+  // (cleared by the call: it keeps the previous call's contents), every launch stays on the caller's stream
+  ctx->launchAll(true, use_mestimator, d_Cx, d_rhs, nullptr, nullptr, (hipStream_t)stream, nullptr, scratchOfDevice(ctx->device), true);
   return 0;
   MC_CATCH(ctx, -1)
 }
