@@ -7,6 +7,7 @@ through the oracle-free properties of tests/gpu_props.py:
               sqrtInvR scaling law
   configs[4]  one rank (3 of 8) of the 600 s stress problem: dimensions, private entries have one writer, gradient of the
               shard's own cost
+  LM          Optimizer2 + Levenberg-Marquardt run to convergence on a 10 s problem against the oracle-side driver
   B8          the dim-6 order-2 BSplineMotionError pose prior (calibrator.py:125-130) in a parity problem
 """
 import numpy as np
@@ -166,3 +167,37 @@ def test_config4_one_rank_of_eight():
     assert not np.any((Cx != 0.0) & (Cx2 != 0.0) & private)
     del g2
     torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
+def test_levenberg_marquardt_to_convergence_matches_oracle():
+    """Optimizer2 + LM to CONVERGENCE (convergenceDeltaX 1e-5, convergenceJDescentRatioThreshold 1e-6 as calibrator.py:27-58
+    sets them, lambda0 = 10) on a 10 s problem: mc_optimize on the GPU against the same loop over the oracle
+    (tests/oracle_lm.py).  Same accepted / rejected sequence, final estimates within 1e-7."""
+    from multical_amd import synth
+    from multical_amd.backend import HipApi
+    from oracle_lm import optimize_lm
+    cfg = synth.SynthConfig(duration=10.0, n_cams=2, n_imus=2, n_lidars=1, lidar_points_per_frame=40, corner_stride=4,
+                            cam_models=[(0, 1), (1, 1)], huber_accel=1.0, huber_gyro=1.0, blake_zisserman_cam=2,
+                            motion_speed=8.0)
+    spec, H, W, meas = synth.make_problem(cfg, lambda: HipApi(0))
+    g = HipApi(0)
+    ids = spec.emit(g)
+    o, oids = _oracle(spec)
+    assert o.j_cols > 6000
+    r = g.optimize(maxIterations=40, convergenceDeltaX=1e-5, convergenceJDescentRatioThreshold=1e-6,
+                   levenbergMarquardtLambdaInit=10.0)
+    ro = optimize_lm(o, 40, 10.0, 1e-5, 1e-6)
+    assert r["iterations"] < 40, "did not converge"
+    assert (r["iterations"], r["failedIterations"]) == (ro["iterations"], ro["failedIterations"]), (r, ro)
+    assert abs(r["JFinal"] - ro["JFinal"]) <= 1e-9 * ro["JFinal"]
+    assert r["JFinal"] < 0.05 * r["JStart"]
+    worst = 0.0
+    for h, v in ids.items():
+        if isinstance(v, int) and spec.ops[h][0] == "dv":
+            worst = max(worst, np.abs(g.dv_params(v) - o.dv_params(oids[h])).max())
+    for key in ("pose",):
+        first, ofirst = g.spline_first_dv(ids[H[key]][1]), o.spline_first_dv(oids[H[key]][1])
+        for i in range(0, W["pose_coeffs"].shape[1], 5):
+            worst = max(worst, np.abs(g.dv_params(first + i) - o.dv_params(ofirst + i)).max())
+    assert worst <= 1e-7, worst
