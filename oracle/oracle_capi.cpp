@@ -622,3 +622,5 @@ int orc_optimize(void* h, int maxIterations, double lambdaInit, double convergen
 }
 
 }  // extern "C"
+
+#include "oracle_unit_capi.hpp"

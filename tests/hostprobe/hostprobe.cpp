@@ -251,3 +251,68 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
 }
 int probe_term_kind(void* h, int term) { Probe* pr = (Probe*)h; return pr->P.batches[pr->term_batch[term]].kind; }
 }
+
+// ---- unit-level access to the product's math (tests/test_oracle_pins.py): the same functions the kernels call
+extern "C" {
+// spline value / derivative of an order-6 spline through spline_weights (mc_math.h) + Problem::basisMatrix; coeffs D x nc column major
+int probe_u_spline_evald(int nk, const double* knots, int D, int nc, const double* coeffs, double t, int d, double* out) {
+  if (d < 0 || d > 2) return -1;
+  std::vector<double> kn(knots, knots + nk);
+  int n_seg = nk - 2 * S6 + 1;
+  if (n_seg < 1 || n_seg + S6 - 1 != nc) return -1;
+  std::vector<double> basis((size_t)n_seg * S6 * S6);
+  for (int s = 0; s < n_seg; ++s) Problem::basisMatrix(kn, S6, s + S6 - 1, &basis[(size_t)s * S6 * S6]);
+  SplineView v;
+  std::memset(&v, 0, sizeof v);
+  v.knots = kn.data(); v.basis = basis.data(); v.n_knots = nk; v.order = S6; v.dim = D; v.n_coeff = nc; v.n_seg = n_seg;
+  v.t_min = kn[S6 - 1]; v.t_max = kn[nk - S6];
+  double w[3][S6];
+  int seg = spline_weights<S6, 3>(v, t, w);
+  if (seg < 0) return -1;
+  for (int i = 0; i < D; ++i) {
+    double a = 0.0;
+    for (int j = 0; j < S6; ++j) a += w[d][j] * coeffs[(size_t)(seg + j) * D + i];
+    out[i] = a;
+  }
+  return seg;
+}
+// S(theta) and d(S(theta) v)/dtheta (rotvec_C_S, rotvec_dSv_dtheta): omega = S v, D 3x3 row major
+int probe_u_rotvec_dSv(const double* th, const double* v, double* omega, double* D) {
+  double Cm[9], S[9];
+  rotvec_C_S(th, Cm, S);
+  m3_mulv(S, v, omega);
+  rotvec_dSv_dtheta(th, v, D);
+  return 0;
+}
+int probe_u_distort(int kind, const double* k, const double* y, double* yd, double* Jy, double* Jk) {
+  double yy[2] = {y[0], y[1]};
+  distort<true>(kind, k, yy, Jy);
+  yd[0] = yy[0]; yd[1] = yy[1];
+  distort_param_jacobian(kind, y, Jk);
+  return 0;
+}
+// Q of the n-th BSplineMotionError batch (describeMotion's band) as a dense (D nc) x (D nc) row-major matrix
+int probe_motion_q(void* h, int which, double* out, int N) {
+  Probe* pr = (Probe*)h;
+  int seen = 0;
+  for (const Batch& b : pr->P.batches) {
+    if (b.kind != KIND_MOTION) continue;
+    if (seen++ != which) continue;
+    const SplineRec& s = pr->P.splines[b.spline];
+    const int D = s.dim, S = s.order;
+    if (N != D * s.n_coeff) return -1;
+    std::fill(out, out + (size_t)N * N, 0.0);
+    for (int i = 0; i < s.n_coeff; ++i)
+      for (int d = 0; d < S && i - d >= 0; ++d) {
+        const double* blk = &b.Qband[((size_t)i * S + d) * D * D];
+        for (int r = 0; r < D; ++r)
+          for (int c = 0; c < D; ++c) {
+            out[(size_t)(i * D + r) * N + (i - d) * D + c] = blk[r * D + c];
+            out[(size_t)((i - d) * D + c) * N + i * D + r] = blk[r * D + c];
+          }
+      }
+    return 0;
+  }
+  return -1;
+}
+}
