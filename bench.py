@@ -54,24 +54,47 @@ def main():
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # N > 1 must fail fast, never stall: every collective carries a time limit, and a watchdog (re-armed at every phase
+    # note) dumps the Python stack of every thread and exits non-zero when a phase makes no progress -- torchrun then
+    # takes the other ranks down.  Limits: MC_BENCH_PHASE_TIMEOUT seconds per phase (default 180).
+    import datetime
+    import faulthandler
+    phase_timeout = float(os.environ.get("MC_BENCH_PHASE_TIMEOUT", "180"))
     if world > 1:
+        pg_timeout = datetime.timedelta(seconds=phase_timeout)
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
 
-    verbose = os.environ.get("MC_BENCH_VERBOSE") == "1"
+    verbose = os.environ.get("MC_BENCH_VERBOSE") == "1" or world > 1
+    trace = os.environ.get("MC_BENCH_TRACE") == "1"      # per-call notes with a device synchronise in between (diagnosis)
 
     def note(msg):
+        if world > 1:
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(phase_timeout, exit=True)
         if verbose:
-            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+            print("[bench rank %d %s] %s" % (rank, time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+    def tr(msg):
+        if trace:
+            torch.cuda.synchronize()
+            note(msg)
 
     base = synth.baseline_config(args.config)
     per_gpu = args.duration if args.duration is not None else base.duration
     cfg = synth.baseline_config(args.config, duration=per_gpu * world)
     t0 = time.time()
     W = synth.make_world(cfg)
-    meas = synth.synthesize(W, lambda: HipApi(local_rank), noise=True)   # forward model at the truth, on this GPU
+    def synth_api():
+        # forward model at the truth, on this GPU.  With shards every rank synthesises the measurements of ITS OWN time window only
+        # (same cuts: they depend on the terms' times and counts, not on the state); the others' stay zero and are never read
+        a = HipApi(local_rank)
+        if world > 1:
+            a.set_shard(rank, world)
+        return a
+    meas = synth.synthesize(W, synth_api, noise=True)
     spec, H = synth.build_spec(W, synth.initial_state(W), meas)
     api = HipApi(local_rank)
     if world > 1:
@@ -80,6 +103,13 @@ def main():
     api.finalize()
     t_setup = time.time() - t0
     note("set-up done in %.1f s, %d terms, nnz %d" % (t_setup, api.n_terms, api.nnz))
+    ranks_seen = None
+    if world > 1:
+        mine = dict(rank=rank, device=torch.cuda.current_device(), name=torch.cuda.get_device_name(), pid=os.getpid())
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
+        assert dist.get_world_size() == world and sorted(r["rank"] for r in ranks_seen) == list(range(world)), ranks_seen
+        note("all %d ranks present" % world)
 
     dev = torch.device("cuda", local_rank)
     dCx = torch.zeros(api.nnz, dtype=torch.float64, device=dev)
@@ -94,23 +124,32 @@ def main():
         # partial Hessians: only the entries two ranks can write (window halos, global x global blocks) are summed;
         # every other entry already sits complete on the rank that owns its time window
         api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
-        if rehearse:
-            h = xbuf.cpu()            # gloo on host memory; its device-tensor staging hung with two ranks on one GPU
+        tr("packed")
+        if rehearse and os.environ.get("MC_BENCH_GLOO_DEVICE") != "1":
+            h = xbuf.cpu()            # gloo on host memory (DESIGN.md section 6 has what its device-tensor path does)
             dist.all_reduce(h)
             xbuf.copy_(h)
         else:
             dist.all_reduce(xbuf)
+        tr("all-reduced")
         api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
+        tr("unpacked")
 
     def step():
         api.evaluate_error_device(True, dJ.data_ptr(), None, stream)
+        tr("evaluated")
         api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), stream)
+        tr("built")
         if world > 1:
             exchange()
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if rehearse:
+                dist.monitored_barrier(timeout=datetime.timedelta(seconds=phase_timeout))
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -147,6 +186,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_fused = tt.item()
     api.check_status()
+    note("fused steps done")
     ms_per_step = dt / args.steps * 1e3
     n_terms = api.n_terms
     value = n_terms / (dt / args.steps)
@@ -174,6 +214,9 @@ def main():
         api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), stream)
     fence()
     build_wall_ms = (time.perf_counter() - t3) / args.steps * 1e3
+    note("per-kernel timing done")
+    if world > 1:
+        faulthandler.cancel_dump_traceback_later()     # what follows is rank-local
     dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
     pk = per_kernel[dom]
     avg_launch_ms = pk["ms"] / max(1, pk["launches"])
@@ -220,7 +263,7 @@ def main():
                            error_terms=n_terms, j_rows=api.j_rows, j_cols=api.j_cols, nnz_upper=api.nnz, n_blocks=api.n_blocks,
                            build_ms=round(build_wall_ms, 4), build_kernels_serial_ms=round(float(ms_build.sum()), 4), evaluate_ms=round(float(ms_eval.sum()), 4),
                            fused_evaluate_and_build_ms=round(dt_fused / args.steps * 1e3, 4),
-                           setup_s=round(t_setup, 2), shared_values=n_shared,
+                           setup_s=round(t_setup, 2), shared_values=n_shared, ranks_seen=ranks_seen,
                            sharding="time windows, global pattern; one RCCL all-reduce of [shared Cx entries | rhs | J] per step" if world > 1 else "none"),
                roofline=roofline)
 
@@ -246,6 +289,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
 
 

@@ -14,8 +14,17 @@
  * Conventions: plain pointers and sizes only; the caller owns every host buffer it passes and
  * the pointers are borrowed for the duration of the call; the context owns all device memory.
  * All arithmetic is IEEE fp64, indices are 32-bit int.  Every function returns 0 on success and
- * a negative code on failure unless stated otherwise; mc_last_error() gives the message.  A
- * context is not thread-safe.  Calls without a `_device` suffix synchronise before returning.
+ * a negative code on failure unless stated otherwise; mc_last_error() gives the message.
+ *
+ * Threads and streams.  A context is not thread-safe and not re-entrant, and it is SINGLE-STREAM: the `_device` entry
+ * points enqueue on the caller's stream and return at once; the library's per-context scratch (per-observation records,
+ * cost partials, replicas of contended entries, chi^2) is shared by all of them, so two `_device` calls of one context must
+ * not be in flight on different streams.  Calls without a `_device` suffix run on the null stream and synchronise before
+ * returning; they first wait for the context's last `_device` call to finish (an event recorded at its end), so
+ * mc_apply_update / mc_revert_update never overwrite the state under running kernels and mc_device_status never reads the
+ * flag before the kernels that set it -- also when the caller's stream does not synchronise with the null stream (torch's
+ * pool streams).  When mc_device_status reports a non-zero status, the outputs of the call that raised it are undefined
+ * (partial sums): the solver classes throw before consuming them, as the reference throws out of evaluateError.
  */
 #ifndef MULTICAL_HIP_H
 #define MULTICAL_HIP_H

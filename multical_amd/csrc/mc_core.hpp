@@ -8,6 +8,8 @@
 // into the final CCS array, and the scalar pattern (Cp, Ci) is emitted in exactly fillCCS order.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -431,6 +433,10 @@ struct Problem {
 
 inline void Problem::finalize() {
   if (finalized) throw std::logic_error("mc_finalize called twice");
+  const bool timing = std::getenv("MC_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tlast = tnow();
+  auto lap = [&](const char* what) { if (timing) { double t = tnow(); std::fprintf(stderr, "[finalize] %-28s %.3f s\n", what, t - tlast); tlast = t; } };
   // ---- Optimizer2::initialize: active dvs in problem order get block index / column base
   n_blocks = 0; j_cols = 0;
   block_dim.clear(); block_col.clear(); block_dv.clear();
@@ -617,17 +623,58 @@ inline void Problem::finalize() {
       }
     }
   }
+  lap("groups + footprints");
   // ---- block pattern: union of all footprints' block pairs + every diagonal block
   // (BlockCholeskyLinearSystemSolver::solveSystem touches block(i,i,true) for all i before fillCCS runs,
   //  BlockCholeskyLinearSystemSolver.cpp:80-81)
   col_rows.assign(n_blocks, std::vector<int>());
   for (int i = 0; i < n_blocks; ++i) col_rows[i].push_back(i);
-  for (const std::vector<int>& pat : fp_pattern)
-    for (size_t j = 0; j < pat.size(); ++j)
-      for (size_t i = 0; i < j; ++i) col_rows[pat[j]].push_back(pat[i]);
-  for (const std::vector<int>& pat : cliques)
-    for (size_t j = 0; j < pat.size(); ++j)
-      for (size_t i = 0; i < j; ++i) col_rows[pat[j]].push_back(pat[i]);
+  {
+    // Every pattern is a sorted block list: a few long runs of consecutive blocks (the frozen coefficient buffers) plus
+    // single blocks (extrinsics, time offsets, board poses ...).  There are millions of distinct ones on a long sequence, so
+    // their pair sets are accumulated by structure instead of pair by pair:
+    //   run [a, b] x itself   column c of the run gets rows a .. c: the union over all runs through c is [min a, c]  -> reach[c]
+    //   single s x run [a, b] one interval per occurrence, merged per single block afterwards                         -> touch[s]
+    //   single x single       pushed directly (at most a handful per pattern)
+    std::vector<int> reach(n_blocks);
+    std::iota(reach.begin(), reach.end(), 0);
+    std::vector<std::vector<std::pair<int, int>>> touch(n_blocks);
+    std::vector<std::pair<int, int>> runs;
+    std::vector<int> singles;
+    auto addPattern = [&](const std::vector<int>& pat) {
+      runs.clear(); singles.clear();
+      for (size_t i = 0; i < pat.size();) {
+        size_t j = i;
+        while (j + 1 < pat.size() && pat[j + 1] == pat[j] + 1) ++j;
+        if (j - i + 1 >= 3) runs.push_back({pat[i], pat[j]});
+        else for (size_t k = i; k <= j; ++k) singles.push_back(pat[k]);
+        i = j + 1;
+      }
+      for (auto& r : runs) for (int c = r.first; c <= r.second; ++c) reach[c] = std::min(reach[c], r.first);
+      for (size_t a = 0; a < runs.size(); ++a)
+        for (size_t b2 = a + 1; b2 < runs.size(); ++b2)          // two runs in one pattern (pose and bias windows)
+          for (int c = runs[b2].first; c <= runs[b2].second; ++c)
+            for (int r = runs[a].first; r <= runs[a].second; ++r) col_rows[c].push_back(r);
+      for (int sgl : singles) for (auto& r : runs) touch[sgl].push_back(r);
+      for (size_t j = 0; j < singles.size(); ++j)
+        for (size_t i = 0; i < j; ++i) col_rows[singles[j]].push_back(singles[i]);
+    };
+    for (const std::vector<int>& pat : fp_pattern) addPattern(pat);
+    for (const std::vector<int>& pat : cliques) addPattern(pat);
+    for (int c = 0; c < n_blocks; ++c) for (int r = reach[c]; r < c; ++r) col_rows[c].push_back(r);
+    for (int sgl = 0; sgl < n_blocks; ++sgl) {
+      std::vector<std::pair<int, int>>& iv = touch[sgl];
+      if (iv.empty()) continue;
+      std::sort(iv.begin(), iv.end());
+      int lo = iv[0].first, hi = iv[0].second;
+      auto flush = [&]() { for (int k = lo; k <= hi; ++k) { if (k < sgl) col_rows[sgl].push_back(k); else if (k > sgl) col_rows[k].push_back(sgl); } };
+      for (size_t i = 1; i < iv.size(); ++i) {
+        if (iv[i].first <= hi + 1) hi = std::max(hi, iv[i].second);
+        else { flush(); lo = iv[i].first; hi = iv[i].second; }
+      }
+      flush();
+    }
+  }
   // motion terms: band blocks between active coefficients (BSplineMotionError.hpp:122-156)
   for (const Batch& b : batches) {
     if (b.kind != KIND_MOTION) continue;
@@ -666,6 +713,7 @@ inline void Problem::finalize() {
         for (int r = 0; r < n; ++r) *ci++ = block_col[rb] + r;
       }
     }
+  lap("block pattern + Cp/Ci");
   // ---- replicas of the contended (global x global) entries
   gcb.assign(n_blocks, -1);
   rep_cols = 0; rep_idx.clear(); rep_addr.clear(); rep_rhs_col.clear();
@@ -704,43 +752,7 @@ inline void Problem::finalize() {
     pat_roff.insert(pat_roff.end(), col_roff[c].begin(), col_roff[c].end());
     pat_colptr[c + 1] = (int)pat_rows.size();
   }
-  // ---- footprint tables
-  auto slotBase = [&](int rb, int cb) {
-    const std::vector<int>& rows = col_rows[cb];
-    size_t k = std::lower_bound(rows.begin(), rows.end(), rb) - rows.begin();
-    return Cp[block_col[cb]] + col_roff[cb][k];
-  };
-  fp_off.assign(fp_written.size(), 0);
-  fp_data.clear();
-  for (size_t f = 0; f < fp_written.size(); ++f) {
-    fp_off[f] = (int)fp_data.size();
-    // written blocks sorted by block index
-    std::vector<std::array<int, 3>> w = fp_written[f];
-    std::vector<std::pair<int, int>> blocks;  // (block index, role) expanded
-    std::vector<int> rolecol(MC_MAX_ROLES, -1);
-    for (auto& e : w) for (int k = 0; k < e[2]; ++k) blocks.push_back({e[1] + k, k == 0 ? e[0] : -1});
-    std::sort(blocks.begin(), blocks.end());
-    int nb = (int)blocks.size();
-    std::vector<int> colstart(nb + 1, 0);
-    for (int i = 0; i < nb; ++i) {
-      colstart[i + 1] = colstart[i] + block_dim[blocks[i].first];
-      if (blocks[i].second >= 0) rolecol[blocks[i].second] = colstart[i];
-    }
-    int C = colstart[nb];
-    fp_data.push_back(nb); fp_data.push_back(C);
-    fp_data.push_back(fp_coef_lo[f]); fp_data.push_back(fp_nbuf[f]);
-    for (int r = 0; r < MC_MAX_ROLES; ++r) fp_data.push_back(rolecol[r]);
-    for (int i = 0; i < nb; ++i) {
-      fp_data.push_back(blocks[i].first); fp_data.push_back(colstart[i]);
-      fp_data.push_back(block_dim[blocks[i].first]); fp_data.push_back(block_col[blocks[i].first]);
-    }
-    for (int ib = 0; ib < nb; ++ib)
-      for (int ia = 0; ia <= ib; ++ia) fp_data.push_back(slotBase(blocks[ia].first, blocks[ib].first));
-    for (int i = 0; i < nb; ++i)
-      for (int c = colstart[i]; c < colstart[i + 1]; ++c) fp_data.push_back(i);
-    for (int i = 0; i < nb; ++i) fp_data.push_back(col_h[blocks[i].first]);   // column height of each block (address stride)
-  }
-  fp_off.push_back((int)fp_data.size());   // sentinel: footprint f spans [fp_off[f], fp_off[f+1])
+  lap("replicas + pattern CSR");
   // ---- shard: contiguous time windows of equal estimated cost over all groups
   {
     struct GT { double t; double cost; };
@@ -812,6 +824,49 @@ inline void Problem::finalize() {
         }
     }
   }
+  lap("shard + chunk tables");
+  // ---- footprint tables (after the shard cut: see fp_used)
+  auto slotBase = [&](int rb, int cb) {
+    const std::vector<int>& rows = col_rows[cb];
+    size_t k = std::lower_bound(rows.begin(), rows.end(), rb) - rows.begin();
+    return Cp[block_col[cb]] + col_roff[cb][k];
+  };
+  fp_off.assign(fp_written.size(), 0);
+  fp_data.clear();
+  // a shard only needs the tables of the footprints its own groups use (a long sequence has millions of footprints)
+  std::vector<char> fp_used(fp_written.size(), world == 1 ? 1 : 0);
+  if (world > 1) for (const Batch& b : batches) for (const GroupRec& g : b.my_groups) fp_used[g.fp] = 1;
+  for (size_t f = 0; f < fp_written.size(); ++f) {
+    fp_off[f] = (int)fp_data.size();
+    if (!fp_used[f]) continue;
+    // written blocks sorted by block index
+    std::vector<std::array<int, 3>> w = fp_written[f];
+    std::vector<std::pair<int, int>> blocks;  // (block index, role) expanded
+    std::vector<int> rolecol(MC_MAX_ROLES, -1);
+    for (auto& e : w) for (int k = 0; k < e[2]; ++k) blocks.push_back({e[1] + k, k == 0 ? e[0] : -1});
+    std::sort(blocks.begin(), blocks.end());
+    int nb = (int)blocks.size();
+    std::vector<int> colstart(nb + 1, 0);
+    for (int i = 0; i < nb; ++i) {
+      colstart[i + 1] = colstart[i] + block_dim[blocks[i].first];
+      if (blocks[i].second >= 0) rolecol[blocks[i].second] = colstart[i];
+    }
+    int C = colstart[nb];
+    fp_data.push_back(nb); fp_data.push_back(C);
+    fp_data.push_back(fp_coef_lo[f]); fp_data.push_back(fp_nbuf[f]);
+    for (int r = 0; r < MC_MAX_ROLES; ++r) fp_data.push_back(rolecol[r]);
+    for (int i = 0; i < nb; ++i) {
+      fp_data.push_back(blocks[i].first); fp_data.push_back(colstart[i]);
+      fp_data.push_back(block_dim[blocks[i].first]); fp_data.push_back(block_col[blocks[i].first]);
+    }
+    for (int ib = 0; ib < nb; ++ib)
+      for (int ia = 0; ia <= ib; ++ia) fp_data.push_back(slotBase(blocks[ia].first, blocks[ib].first));
+    for (int i = 0; i < nb; ++i)
+      for (int c = colstart[i]; c < colstart[i + 1]; ++c) fp_data.push_back(i);
+    for (int i = 0; i < nb; ++i) fp_data.push_back(col_h[blocks[i].first]);   // column height of each block (address stride)
+  }
+  fp_off.push_back((int)fp_data.size());   // sentinel: footprint f spans [fp_off[f], fp_off[f+1])
+  lap("footprint tables");
   // ---- shared entries (world > 1): owner rank of every block pair over ALL ranks' work items
   shared_idx.clear();
   if (world > 1) {
@@ -890,9 +945,12 @@ inline void Problem::finalize() {
       }
     std::sort(shared_idx.begin(), shared_idx.end());
   }
+  lap("shared entries");
   // ---- J^T (SparseCholesky backend) layout: elements per column and first value index of every term
   jt_start.assign(n_terms + 1, 0); jt_epc.assign(n_terms, 0); jt_supported = true;
+  if (world > 1) jt_supported = false;   // the J^T backend is single-GPU (and the other shards' footprint tables are not built)
   for (const Batch& b : batches) {
+    if (world > 1) break;
     if (b.kind == KIND_MOTION) { jt_supported = false; continue; }   // BSplineMotionError has no evaluateJacobians in the reference either
     for (const GroupRec& g : b.groups) {
       int C = fp_data[fp_off[g.fp] + 1];
@@ -915,6 +973,7 @@ inline void Problem::finalize() {
     jt_start[n_terms] = acc;
     jt_nnz = acc;
   }
+  lap("J^T layout");
   update_dvs = block_dv;
   finalized = true;
 }

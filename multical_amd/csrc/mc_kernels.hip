@@ -1399,9 +1399,17 @@ struct mc_context {
   hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr, nullptr, nullptr};
   int side_state = 0;   // 0: not created yet, 1: ready, -1: disabled
+  // Stream contract.  The *_device entry points enqueue on the caller's stream and return; everything else (apply / revert,
+  // status, parameter and chi^2 read-back) runs on the null stream, and torch's pool streams do not synchronise with it.  The
+  // end of every launch sequence is marked with this event and the null-stream entry points wait for it first, so an update can
+  // never overwrite x while build kernels still read it and a status read never precedes the kernels that set it.
+  hipEvent_t ev_done = nullptr;
+  bool done_recorded = false;
+  void waitForLaunches() { if (done_recorded) HIP_CHECK(hipEventSynchronize(ev_done)); }
   ~mc_context() {
     for (int i = 0; i < N_SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_done) (void)hipEventDestroy(ev_done);
   }
   bool sideStreams() {
     if (side_state == 0) {
@@ -1471,6 +1479,7 @@ void batchCounts(const Problem& P, const Batch& b, double& fd, double& fl, doubl
 
 void mc_context::uploadStructure() {
   HIP_CHECK(hipSetDevice(device));
+  if (!ev_done) HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
   x.upload(P.x);
   x_prev.alloc(P.x.size());
   knots.upload(P.knots);
@@ -1767,6 +1776,12 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   bool used[N_SIDE] = {false, false, false};
   const bool fork = !ev && !serial && sideStreams();
   if (fork) HIP_CHECK(hipEventRecord(ev_fork, caller));
+  // a failure between fork and join must not leave the side streams running unjoined behind the caller's back
+  auto joinSides = [&]() {
+    for (int s = 0; s < N_SIDE; ++s)
+      if (used[s]) { HIP_CHECK(hipEventRecord(ev_join[s], side[s])); HIP_CHECK(hipStreamWaitEvent(caller, ev_join[s], 0)); used[s] = false; }
+  };
+  try {
   for (int l = 0; l < N_LAUNCH; ++l) {
     LaunchUnit& L = lu[l];
     if (ev) HIP_CHECK(hipEventRecord((*ev)[l], caller));
@@ -1824,9 +1839,12 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     }
     HIP_CHECK(hipGetLastError());
   }
+  } catch (...) {
+    try { joinSides(); } catch (...) {}
+    throw;
+  }
   st = caller;
-  for (int s = 0; s < N_SIDE; ++s)
-    if (used[s]) { HIP_CHECK(hipEventRecord(ev_join[s], side[s])); HIP_CHECK(hipStreamWaitEvent(st, ev_join[s], 0)); }
+  joinSides();
   if (ev) HIP_CHECK(hipEventRecord((*ev)[N_LAUNCH], st));
   if (use_rep) {
     const int n = (int)P.rep_idx.size();
@@ -1845,6 +1863,8 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     }
     HIP_CHECK(hipGetLastError());
   }
+  HIP_CHECK(hipEventRecord(ev_done, st));
+  done_recorded = true;
 }
 
 void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
@@ -1888,6 +1908,8 @@ void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
     hipLaunchKernelGGL(k_jt_stream<LidarBatchView>, dim3(L.n_items), dim3(128), 0, st, L.lviews.p, dc, L.chunks.p, jt);
   }
   HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(ev_done, st));
+  done_recorded = true;
 }
 
 #define MC_TRY try {
@@ -2188,12 +2210,14 @@ int mc_launch_counts(const mc_context* ctx, int launch, double* flops_dense, dou
 int mc_build_system_timed(mc_context* ctx, int use_mestimator, int build, float* ms_per_launch) {
   MC_TRY MC_NEED_FINAL(ctx);
   HIP_CHECK(hipSetDevice(ctx->device));
-  std::vector<hipEvent_t> ev(N_LAUNCH + 1);
-  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
-  ctx->launchAll(build, use_mestimator, ctx->Cx.p, ctx->rhs.p, build ? nullptr : ctx->J.p, nullptr, 0, &ev);
+  struct Events {   // destroyed on every path out
+    std::vector<hipEvent_t> ev;
+    explicit Events(size_t n) : ev(n, nullptr) { for (auto& e : ev) HIP_CHECK(hipEventCreate(&e)); }
+    ~Events() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+  } evs(N_LAUNCH + 1);
+  ctx->launchAll(build, use_mestimator, ctx->Cx.p, ctx->rhs.p, build ? nullptr : ctx->J.p, nullptr, 0, &evs.ev);
   HIP_CHECK(hipStreamSynchronize(0));
-  for (int i = 0; i < N_LAUNCH; ++i) HIP_CHECK(hipEventElapsedTime(&ms_per_launch[i], ev[i], ev[i + 1]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
+  for (int i = 0; i < N_LAUNCH; ++i) HIP_CHECK(hipEventElapsedTime(&ms_per_launch[i], evs.ev[i], evs.ev[i + 1]));
   return 0;
   MC_CATCH(ctx, -1)
 }
@@ -2225,6 +2249,7 @@ int mc_get_term_chi2(mc_context* ctx, double* chi2_out) {
 int mc_apply_update(mc_context* ctx, const double* dx) {
   MC_TRY MC_NEED_FINAL(ctx);
   HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->waitForLaunches();   // kernels enqueued on the caller's stream may still read x
   HIP_CHECK(hipMemcpyAsync(ctx->x_prev.p, ctx->x.p, sizeof(double) * ctx->P.x.size(), hipMemcpyDeviceToDevice, 0));
   HIP_CHECK(hipMemcpyAsync(ctx->dx.p, dx, sizeof(double) * ctx->P.j_cols, hipMemcpyHostToDevice, 0));
   int n = (int)ctx->upd.n;
@@ -2239,6 +2264,7 @@ int mc_revert_update(mc_context* ctx) {
   MC_TRY MC_NEED_FINAL(ctx);
   if (!ctx->have_prev) throw std::logic_error("no update to revert");
   HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->waitForLaunches();
   HIP_CHECK(hipMemcpy(ctx->x.p, ctx->x_prev.p, sizeof(double) * ctx->P.x.size(), hipMemcpyDeviceToDevice));
   return 0;
   MC_CATCH(ctx, -1)
@@ -2249,6 +2275,7 @@ int mc_get_dv_params(mc_context* ctx, int dv, double* out) {
   const DvRec& d = ctx->P.dvs[dv];
   if (ctx->P.finalized) {
     HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->waitForLaunches();
     HIP_CHECK(hipMemcpy(out, ctx->x.p + d.off, sizeof(double) * d.nparam, hipMemcpyDeviceToHost));
   } else std::memcpy(out, &ctx->P.x[d.off], sizeof(double) * d.nparam);
   return d.nparam;
@@ -2297,6 +2324,7 @@ int mc_lidar_find_points_on_targets(mc_context* ctx, int pose_spline, int dv_tim
 int mc_device_status(mc_context* ctx) {
   MC_TRY MC_NEED_FINAL(ctx);
   HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->waitForLaunches();   // the flag is set by kernels that may still be running on the caller's stream
   int s = 0;
   HIP_CHECK(hipMemcpy(&s, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
   if (s) HIP_CHECK(hipMemset(ctx->status.p, 0, sizeof(int)));

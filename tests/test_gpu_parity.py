@@ -391,3 +391,41 @@ def test_medium_problem_properties():
     a2, r2 = g2.build_system(False)
     _close(a2, 4.0 * a1, 1e-12)
     _close(r2, 4.0 * r1, 1e-12)
+
+
+def test_non_default_stream_build_update_status(small_problem, small_oracle):
+    """Stream contract (include/multical_hip.h): the _device entry points run on a torch POOL stream (non-blocking with
+    respect to the null stream); apply / revert / status / read-back run on the null stream and must order themselves
+    after the kernels.  Build on the side stream, apply an update at once, rebuild, compare with the oracle."""
+    import torch
+    g, ids = _hip(small_problem["spec"])
+    o, oids = small_oracle
+    rng = np.random.default_rng(9)
+    dx = 1e-3 * rng.standard_normal(g.j_cols)
+    side = torch.cuda.Stream()
+    dCx = torch.zeros(g.nnz, dtype=torch.float64, device="cuda:0")
+    drhs = torch.zeros(g.j_cols, dtype=torch.float64, device="cuda:0")
+    dJ = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    o.evaluate_error(True)
+    Cp, Ci, Cx0, rhs0 = o.build_system(True)
+    o.apply_update(dx)
+    try:
+        Jo, _ = o.evaluate_error(True)
+        _, _, Cx1, rhs1 = o.build_system(True)
+    finally:
+        o.revert_update()
+        o.evaluate_error(True)
+    with torch.cuda.stream(side):
+        st = side.cuda_stream
+        for _ in range(3):     # keep the side stream busy so that an unordered update would land under running kernels
+            g.evaluate_error_and_build_system_device(True, dJ.data_ptr(), None, dCx.data_ptr(), drhs.data_ptr(), st)
+        a0 = dCx.clone()
+        g.apply_update(dx)                     # null stream; must wait for the three builds above
+        g.evaluate_error_and_build_system_device(True, dJ.data_ptr(), None, dCx.data_ptr(), drhs.data_ptr(), st)
+        g.check_status()                       # must see the kernels of the call just enqueued
+        side.synchronize()
+    _close(a0.cpu().numpy(), Cx0)
+    _close(dCx.cpu().numpy(), Cx1)
+    _close(drhs.cpu().numpy(), rhs1)
+    assert abs(dJ.item() - Jo) <= RTOL * Jo
+    g.revert_update()
