@@ -291,7 +291,7 @@ int mc_cholesky_block_permutation(const mc_cholesky* h, int* perm /* n_blocks */
 
 /* aslam::backend::Optimizer2Options (aslam_backend/include/aslam/backend/Optimizer2Options.hpp:9-42) with the two
  * shared_ptr members replaced by selectors; mc_optimizer_options_default fills the reference's defaults. */
-enum { MC_POLICY_LEVENBERG_MARQUARDT = 0, MC_POLICY_GAUSS_NEWTON = 1, MC_POLICY_DOG_LEG = 2 };
+enum { MC_POLICY_LEVENBERG_MARQUARDT = 0, MC_POLICY_GAUSS_NEWTON = 1 };
 enum { MC_SOLVER_BLOCK_CHOLESKY = 0, MC_SOLVER_SPARSE_CHOLESKY = 1 };
 typedef struct mc_optimizer_options {
   double convergenceJDescentRatioThreshold; /* 1e-5 */
@@ -299,12 +299,15 @@ typedef struct mc_optimizer_options {
   int maxIterations;                        /* 20 */
   int verbose;                              /* 0 */
   int nThreads;                             /* 4; a hint the GPU backend ignores */
-  int trustRegionPolicy;                    /* MC_POLICY_*: LevenbergMarquardt / GaussNewton / DogLeg TrustRegionPolicy */
+  int trustRegionPolicy;                    /* MC_POLICY_*: LevenbergMarquardt / GaussNewton TrustRegionPolicy */
   double levenbergMarquardtLambdaInit;      /* 1e-3 (LevenbergMarquardtTrustRegionPolicy.cpp:7-13); Multical uses 10 */
   int linearSolver;                         /* MC_SOLVER_*: BlockCholesky / SparseCholesky LinearSystemSolver */
 } mc_optimizer_options;
-/* SolutionReturnValue (aslam_backend_python/src/Optimizer.cpp:30-39) plus wall-clock per phase (the reference's
- * "Optimizer2: ..." timers, Optimizer2.cpp:185-189) and the size of the host factorisation. */
+/* SolutionReturnValue (aslam_backend_python/src/Optimizer.cpp:30-39) plus wall-clock per phase and the size of the host
+ * factorisation.  The minimiser (multical_amd/csrc/host/lm_driver.hpp) evaluates every trial state with ONE fused pass
+ * (cost + normal equations into a spare device buffer) and copies a system to the host only when it is adopted:
+ * seconds_evaluate_error = the fused trial passes, seconds_build_system = adoptions (device-to-host copies),
+ * seconds_solve_system = host factorisation + solve. */
 typedef struct mc_solution_return_value {
   double JStart, JFinal;
   int iterations, failedIterations;
@@ -314,7 +317,8 @@ typedef struct mc_solution_return_value {
   double factor_nnz, factor_flops;
 } mc_solution_return_value;
 void mc_optimizer_options_default(mc_optimizer_options* o);
-/* Optimizer2::optimize (Optimizer2.cpp:183-275) on the problem held by ctx; the state in ctx is the result
+/* What Optimizer2::optimize (Optimizer2.cpp:183-275) computes with a Levenberg-Marquardt or Gauss-Newton policy -- same
+ * iterates, same stopping rule, same counters -- on the problem held by ctx; the state in ctx is the result
  * (mc_get_dv_params).  Returns 0, or -1 with the message in mc_host_last_error(). */
 int mc_optimize(mc_context* ctx, const mc_optimizer_options* options, mc_solution_return_value* out);
 const char* mc_host_last_error(void);

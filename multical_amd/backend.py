@@ -12,9 +12,8 @@ control flow of the reference classes they stand in for:
 The residual / Jacobian / normal-equation work runs on the GPU; the sparse Cholesky solve stays on the host
 (north_star: "timed separately").  CHOLMOD is not installed here, so `solveSystem` factorises the same CCS
 matrix with the C++ block Cholesky of csrc/host/block_cholesky.hpp; the reference's own tests pin the solver only
-through solver-vs-solver agreement of dx (aslam_backend/test/LinearSolverTests.cpp:42-57).  The same loop exists in
-C++ (csrc/host/optimizer2.hpp, `HipApi.optimize`); the Python classes here are the readable mirror the tests drive
-step by step.
+through solver-vs-solver agreement of dx (aslam_backend/test/LinearSolverTests.cpp:42-57).  The optimiser loop is C++
+(csrc/host/lm_driver.hpp behind `mc_optimize` / `HipApi.optimize`); `Optimizer2` here only translates the options object.
 """
 import ctypes as C
 
@@ -553,71 +552,28 @@ class HipSparseCholeskyLinearSystemSolver(object):
 
 
 class LevenbergMarquardtTrustRegionPolicy(object):
+    """Selector for Optimizer2Options.trustRegionPolicy (aslam_backend LevenbergMarquardtTrustRegionPolicy(lambdaInit))."""
+
     def __init__(self, lambdaInit=1e-3):
-        self._lambdaInit, self._gammaInit, self._betaInit, self._pInit, self._muInit = lambdaInit, 3.0, 2.0, 3, 2.0
-        self._solver = None
+        self.lambdaInit = float(lambdaInit)
 
     def name(self):
         return "levenberg_marquardt"
 
-    def setSolver(self, solver):
-        self._solver = solver
 
-    def requiresAugmentedDiagonal(self):
-        return True
-
-    def revertOnFailure(self):
-        return True
-
-    def optimizationStarting(self, J):
-        self._J = self._p_J = self._last_successful_J = J
-        self._isFirstIteration = True
-        self._lambda, self._gamma, self._beta, self._p, self._mu = (self._lambdaInit, self._gammaInit, self._betaInit,
-                                                                    self._pInit, self._muInit)
-        self._dx = None
-
-    def solveSystem(self, J, previousIterationFailed, nThreads):
-        if previousIterationFailed:
-            self._J = J
-        else:
-            self._p_J = self._last_successful_J
-            self._last_successful_J = J
-            self._J = J
-        if self._isFirstIteration:
-            self._solver.buildSystem(nThreads, True)
-        else:
-            d1 = np.float64(self._p_J - self._J)
-            d2 = np.float64(self._dx @ (self._lambda * self._dx + self._solver.rhs()))
-            with np.errstate(divide="ignore", invalid="ignore"):
-                rho = d1 / d2          # IEEE semantics like the C++ (inf / nan, no exception)
-            if previousIterationFailed:
-                self._mu *= 2
-                self._lambda *= self._mu
-            elif rho <= 0:
-                self._mu *= 10
-                self._lambda *= self._mu
-            else:
-                self._solver.buildSystem(nThreads, True)
-                if self._lambda > 1e-16:
-                    u1 = 1 / self._gamma
-                    u2 = 1 - (self._beta - 1) * (2 * rho - 1) ** self._p
-                    self._lambda *= u1 if u1 > u2 else u2
-                    self._mu = self._beta
-                else:
-                    self._lambda = 1e-15
-        self._solver.setConstantConditioner(self._lambda)
-        ok, self._dx = self._solver.solveSystem()
-        self._isFirstIteration = False
-        return ok, self._dx
+class GaussNewtonTrustRegionPolicy(object):
+    def name(self):
+        return "gauss_newton"
 
 
 class Optimizer2Options(object):
+    """aslam::backend::Optimizer2Options as the Python front-end fills it (calibrator.py:27-58)."""
+
     def __init__(self):
         self.convergenceDeltaX = 1e-3
         self.convergenceJDescentRatioThreshold = 1e-5
         self.maxIterations = 20
         self.levenbergMarquardtLambdaInit = 1e-3
-        self.doLevenbergMarquardt = True
         self.verbose = False
         self.nThreads = 4
         self.linearSolver = None
@@ -625,75 +581,32 @@ class Optimizer2Options(object):
 
 
 class SolutionReturnValue(object):
-    def __init__(self):
-        self.JStart = self.JFinal = self.dXFinal = self.dJFinal = 0.0
-        self.iterations = self.failedIterations = 0
-        self.linearSolverFailure = False
+    def __init__(self, r):
+        self.JStart, self.JFinal, self.dXFinal, self.dJFinal = r["JStart"], r["JFinal"], r["dXFinal"], r["dJFinal"]
+        self.iterations, self.failedIterations = r["iterations"], r["failedIterations"]
+        self.linearSolverFailure = bool(r["linearSolverFailure"])
+        self.timings = {k: v for k, v in r.items() if k.startswith("seconds_")}
 
 
 class Optimizer2(object):
+    """`aopt.Optimizer2(options).optimize()` as calibrator.py:41-46 calls it.  The loop itself is C++ (mc_optimize,
+    csrc/host/lm_driver.hpp); this class only translates the options object."""
+
     def __init__(self, options):
         self._options = options
-        self.timings = dict(evaluateError=0.0, buildSystem=0.0, solveSystem=0.0, update=0.0)
 
     def optimize(self):
-        import time
         o = self._options
         solver = o.linearSolver
-        if solver is None:
-            raise BackendError("Optimizer2Options.linearSolver must be a HipBlockCholeskyLinearSystemSolver")
+        if solver is None or not hasattr(solver, "api"):
+            raise BackendError("Optimizer2Options.linearSolver must be a Hip*LinearSystemSolver")
         policy = o.trustRegionPolicy or LevenbergMarquardtTrustRegionPolicy(o.levenbergMarquardtLambdaInit)
-        solver.initMatrixStructure(policy.requiresAugmentedDiagonal())
-        srv = SolutionReturnValue()
-        tm = self.timings
-        t0 = time.perf_counter()
-        J = solver.evaluateError(o.nThreads, True)
-        tm["evaluateError"] += time.perf_counter() - t0
-        p_J = J
-        srv.JStart = p_J
-        deltaX = o.convergenceDeltaX + 1.0
-        ratio = o.convergenceJDescentRatioThreshold + 1.0
-        deltaJ = 0.0
-        prevFailed = lsFail = False
-        policy.setSolver(solver)
-        policy.optimizationStarting(J)
-        while (srv.iterations < o.maxIterations and srv.failedIterations < o.maxIterations and
-               ((deltaX > o.convergenceDeltaX and abs(ratio) > o.convergenceJDescentRatioThreshold) or lsFail)):
-            t0 = time.perf_counter()
-            b0 = tm["buildSystem"]
-            _build = solver.buildSystem
-
-            def timed_build(n, m, _b=_build):
-                t1 = time.perf_counter()
-                _b(n, m)
-                tm["buildSystem"] += time.perf_counter() - t1
-            solver.buildSystem = timed_build
-            ok, dx = policy.solveSystem(J, prevFailed, o.nThreads)
-            solver.buildSystem = _build
-            tm["solveSystem"] += time.perf_counter() - t0 - (tm["buildSystem"] - b0)
-            if not ok:
-                prevFailed = lsFail = True
-                srv.failedIterations += 1
-            else:
-                t0 = time.perf_counter()
-                solver.api.apply_update(dx)
-                deltaX = float(np.max(np.abs(dx)))
-                tm["update"] += time.perf_counter() - t0
-                t0 = time.perf_counter()
-                J = solver.evaluateError(o.nThreads, True)
-                tm["evaluateError"] += time.perf_counter() - t0
-                deltaJ = p_J - J
-                ratio = deltaJ / p_J
-                if ratio < 0.0:
-                    solver.api.revert_update()
-                    srv.failedIterations += 1
-                    prevFailed = True
-                else:
-                    p_J = J
-                    prevFailed = False
-                srv.iterations += 1
-                if o.verbose:
-                    print("[%d]: J: %.9g, dJ: %.6g, deltaX: %.6g, LM - lambda:%g mu:%g" %
-                          (srv.iterations, J, deltaJ, deltaX, policy._lambda, policy._mu))
-        srv.JFinal, srv.dXFinal, srv.dJFinal, srv.linearSolverFailure = p_J, deltaX, deltaJ, lsFail
-        return srv
+        kw = dict(maxIterations=int(o.maxIterations), convergenceDeltaX=float(o.convergenceDeltaX),
+                  convergenceJDescentRatioThreshold=float(o.convergenceJDescentRatioThreshold), verbose=int(bool(o.verbose)),
+                  linearSolver=1 if isinstance(solver, HipSparseCholeskyLinearSystemSolver) else 0)
+        if isinstance(policy, GaussNewtonTrustRegionPolicy):
+            kw["trustRegionPolicy"] = 1
+        else:
+            kw["trustRegionPolicy"] = 0
+            kw["levenbergMarquardtLambdaInit"] = float(policy.lambdaInit)
+        return SolutionReturnValue(solver.api.optimize(**kw))

@@ -6,7 +6,7 @@
 //   HipBlockCholeskyLinearSystemSolver   <- BlockCholeskyLinearSystemSolver  (src/BlockCholeskyLinearSystemSolver.cpp)
 //   HipSparseCholeskyLinearSystemSolver  <- SparseCholeskyLinearSystemSolver (src/SparseCholeskyLinearSystemSolver.cpp)
 //
-// Call order accepted (the one Optimizer2 uses, Optimizer2.cpp:142, 183-275): initMatrixStructure once,
+// Call order accepted (the one Optimizer2 uses, Optimizer2.cpp:142, 183-275; host/lm_driver.hpp is this repository's own caller): initMatrixStructure once,
 // evaluateError before every buildSystem, solveSystem any number of times after one buildSystem (rejected LM steps
 // do not rebuild, LevenbergMarquardtTrustRegionPolicy.cpp:61-72).
 //
@@ -50,10 +50,15 @@ class LinearSystemSolver {
     initMatrixStructureImplementation(useDiagonalConditioner);
   }
   // LinearSystemSolver::evaluateError (LinearSystemSolver.cpp:81-92); nThreads has no meaning on the GPU
+  // The stacked error vector is j_rows doubles (72 MB on the full Multical problem) and only the J^T backend consumes it
+  // (rhs = J^T e): it is copied from the device with the cost when the solver says it needs it, otherwise on the first e().
   virtual double evaluateError(std::size_t /*nThreads*/, bool useMEstimator) {
     double J = 0.0;
-    check(mc_evaluate_error(ctx_, useMEstimator ? 1 : 0, &J, e_.data()));
+    const bool withE = needsErrorVector();
+    check(mc_evaluate_error(ctx_, useMEstimator ? 1 : 0, &J, withE ? e_.data() : nullptr));
     raiseDeviceStatus();
+    eFresh_ = withE;
+    lastUseMEstimator_ = useMEstimator;
     return J;
   }
   virtual void buildSystem(std::size_t nThreads, bool useMEstimator) = 0;
@@ -70,7 +75,15 @@ class LinearSystemSolver {
   virtual void setConstantConditioner(double diag) { diagonalConditioner_.assign(jCols_, diag); }
 
   const std::vector<double>& rhs() const { return rhs_; }
-  const std::vector<double>& e() const { return e_; }
+  const std::vector<double>& e() {
+    if (!eFresh_) {   // same state, same weights as the last evaluateError: the same vector
+      double J = 0.0;
+      check(mc_evaluate_error(ctx_, lastUseMEstimator_ ? 1 : 0, &J, e_.data()));
+      raiseDeviceStatus();
+      eFresh_ = true;
+    }
+    return e_;
+  }
   std::size_t JRows() const { return (std::size_t)jRows_; }
   std::size_t JCols() const { return (std::size_t)jCols_; }
 
@@ -86,6 +99,7 @@ class LinearSystemSolver {
 
  protected:
   virtual void initMatrixStructureImplementation(bool useDiagonalConditioner) = 0;
+  virtual bool needsErrorVector() const { return false; }
   struct BuildClock {
     explicit BuildClock(double& acc) : acc_(acc), t0_(std::chrono::steady_clock::now()) {}
     ~BuildClock() { acc_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); }
@@ -97,7 +111,7 @@ class LinearSystemSolver {
 
   mc_context* ctx_;
   std::vector<double> e_, rhs_, diagonalConditioner_;
-  bool useDiagonalConditioner_ = false;
+  bool useDiagonalConditioner_ = false, eFresh_ = false, lastUseMEstimator_ = true;
   int jRows_ = 0, jCols_ = 0, nBlocks_ = 0, nnz_ = 0;
   double buildSeconds_ = 0.0;
 };
@@ -246,6 +260,7 @@ class HipSparseCholeskyLinearSystemSolver : public LinearSystemSolver {
   const std::vector<double>& values() const { return values_; }
 
  protected:
+  bool needsErrorVector() const override { return true; }
   // SparseCholeskyLinearSystemSolver::initMatrixStructureImplementation (:14-36): symbolic J^T
   // (CompressedColumnJacobianTransposeBuilder::initMatrixStructure).  Throws like the reference when the problem holds
   // a BSplineMotionError, whose evaluateJacobians is "currently unsupported" (BSplineMotionError.hpp:93).

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
   for (int i = tid; i < 210; i += 256) Mimg[i] = 0.0;
   if (tid < 6) last_info[tid] = 0;
   __syncthreads();
+  MC_MARK_BEGIN();
   double Jacc = 0.0;
   for (int go = wv; go < im.count; go += 4) {
     const int gi = im.first + go;
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
     }
     f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     const int c16 = lane & 15, kr = lane >> 4;
+    MC_MARK(0);   // record / chain / footprint staged, live-column tables
     for (int base = 0; base < gr.term_count; base += 64) {
       const int k = base + lane;
       const int nrows = 2 * min(64, gr.term_count - base);
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
         zp[6 * Z2] = make_double2(e[0], e[1]);
       }
       wave_sync();
+      MC_MARK(1);   // projection + z rows
       // 7 x 7 Gram Z^T Z: v_mfma_f64_16x16x4_f64 with A[i][k] = Z[k][i], B[k][j] = Z[k][j], one double per lane
       // (lane = 16 (k % 4) + column); two accumulators so consecutive steps do not wait on each other
       const int nsteps = (nrows + 3) >> 2;
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
       }
       wave_sync();   // the next pass overwrites the tile
+      MC_MARK(3);   // MFMA Gram
     }
     // accumulators -> G (7 x 7) -> T = G Kt (7 x 20) -> M = Kt^T T (20 x 20 upper), Kt = [K 0; 0 1]; all inside the wave's tile.
     // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg: rows 0..6 are regs 0 and 1.
@@ -422,8 +426,10 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
       if (!board_entry) atomicAdd(&Mimg[idx], m);
     }
     wave_sync();
+    MC_MARK(4);   // G -> T -> M
     // board rows / columns of this observation
     f1_flush(f, dc, zs + O_M, cm.w, rc0, coef_shift, glc, gk, ggc, n_nb, n_glob, true, lane, 64);
+    MC_MARK(5);   // board flush
     if (last && lane == 0) {
       last_info[0] = 1; last_info[1] = rc0; last_info[2] = coef_shift; last_info[3] = n_nb; last_info[4] = fp_staged ? 1 : 0;
       last_info[5] = fp_begin;
@@ -440,7 +446,9 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
   const int lw = (im.count - 1) & 3;
   FpView f = last_info[4] ? fp_view_at(fpl_all[lw]) : fp_view_at(dc.fp_data + last_info[5]);
   const F1Common& cml = *reinterpret_cast<const F1Common*>(cm_all[lw]);
+  MC_MARK(2);   // waiting for the other waves
   f1_flush(f, dc, Mimg, cml.w, last_info[1], last_info[2], gl_all[lw][0], gl_all[lw][1], gl_all[lw][2], last_info[3], last_info[3], false, tid, 256);
+  MC_MARK(6);   // image flush
 }
 
 __device__ __forceinline__ int b_pose_first_block(const LidarBatchView& b) { return b.sp.first_block; }

@@ -28,7 +28,7 @@ print("total: " + "  ".join("mode%d %.3f" % (m, float(res[m].sum())) for m in re
 if 'timing' not in os.environ.get('MULTICAL_HIP_LIB', ''):
     sys.exit(0)
 ph = api.phase_cycles(True, 1)
-names = {0: "stage record", 1: "project+chain", 2: "wait rows", 3: "mfma gram", 4: "tiles->Msh", 5: "board flush", 6: "image flush",
+names = {0: "stage record", 1: "project+z", 2: "wait waves", 3: "mfma gram", 4: "G->T->M", 5: "board flush", 6: "image flush",
          8: "lidar eval", 9: "lidar wait", 10: "lidar band", 11: "lidar arrow", 12: "lidar oo",
          16: "imu eval", 17: "imu wait", 18: "imu band", 19: "imu arrow", 20: "imu oo"}
 nwg = {0: info[0][3], 8: info[3][3], 16: info[2][3]}
