@@ -288,7 +288,9 @@ def main():
         out["config"]["host_cholesky"] = s._host.stats()
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args, synth)
+        out["cpu_baseline"], out["cpu_optimised"] = cpu_baseline(args, synth)
+        out["speedup_vs_cpu"] = dict(reference_shaped=round(value / out["cpu_baseline"]["value"], 1),
+                                     optimised=round(value / out["cpu_optimised"]["value"], 1))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -297,12 +299,21 @@ def main():
 
 
 def cpu_baseline(args, synth):
-    """The CPU oracle (a restatement in the reference's cost shape: per-term expression-DAG walk with heap matrices,
-    std::map JacobianContainer / SparseBlockMatrix, SERIAL buildSystem, evaluateError on nproc-1 threads) timed on a
-    bounded sample: the first `cpu_sample_seconds` of the same workload."""
+    """Two CPU baselines on the GPU box's host cores, both on a bounded sample (the first `cpu_sample_seconds` of the same
+    workload), both restatements -- the reference binary cannot be built here:
+
+    reference-shaped ("port")  the CPU oracle: per-term expression-DAG walk with heap matrices, std::map JacobianContainer /
+                  SparseBlockMatrix, buildSystem SERIAL on one core (BlockCholeskyLinearSystemSolver.cpp:58-72 ignores
+                  nThreads), evaluateError on nproc - 1 threads like calibrator.py:33 sets it
+    optimised     this repository's own formulation compiled for the host (closed forms, chunk tiles, 7 x 7 Gram + chain
+                  matrix, slot tables) with OpenMP on all cores: tests/hostprobe/cpu_optimised.inc
+    """
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_api import OracleApi
+    from probe_api import ProbeApi
     from multical_amd.backend import HipApi
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count() or 1
     cfg = synth.baseline_config(args.config, duration=args.cpu_sample_seconds)
     W = synth.make_world(cfg)
     meas = synth.synthesize(W, lambda: HipApi(0), noise=True)
@@ -310,20 +321,34 @@ def cpu_baseline(args, synth):
     o = OracleApi()
     spec.emit(o)
     o.finalize()
-    # evaluateError on ONE thread: the oracle's terms share expression nodes whose cached operands are heap matrices, so the
-    # reference's thread fan-out (LinearSystemSolver.cpp:50-78) is not safe on it; buildSystem, which dominates, is serial
-    # in the reference itself
-    o.evaluate_error(True, False, 1)
+    nt = max(1, cores - 1)
+    o.evaluate_error(True, False, nt)
     t = time.perf_counter()
-    o.evaluate_error(True, False, 1)
+    o.evaluate_error(True, False, nt)
     t_eval = time.perf_counter() - t
     t = time.perf_counter()
     o.build_only(True)
     t_build = time.perf_counter() - t
-    return dict(value=o.n_terms / (t_eval + t_build), unit="error-terms/s", cores=1, kind="port",
+    base = dict(value=o.n_terms / (t_eval + t_build), unit="error-terms/s", cores=nt, kind="port",
                 sample="first %.1f s of the same workload (%d error terms): buildSystem serial on 1 core as in the reference "
-                       "(%.3f s), evaluateError on 1 thread (%.3f s)" % (args.cpu_sample_seconds, o.n_terms, t_build, t_eval),
-                build_terms_per_s=o.n_terms / t_build, evaluate_threads=1)
+                       "(%.3f s), evaluateError on %d threads (%.3f s)" % (args.cpu_sample_seconds, o.n_terms, t_build, nt, t_eval),
+                build_terms_per_s=o.n_terms / t_build, evaluate_threads=nt)
+    p = ProbeApi()
+    spec.emit(p)
+    p.finalize()
+    p.cpu_optimised(True, True, cores)
+    reps = 5
+    t = time.perf_counter()
+    for _ in range(reps):
+        p.cpu_optimised(True, True, cores)
+    t_opt = (time.perf_counter() - t) / reps
+    t = time.perf_counter()
+    p.cpu_optimised(True, True, 1)
+    t_opt1 = time.perf_counter() - t
+    opt = dict(value=p.n_terms / t_opt, unit="error-terms/s", cores=cores, kind="port (this repository's formulation, OpenMP)",
+               sample="same sample; one fused evaluateError + buildSystem pass in %.4f s on %d threads (%.4f s on 1 thread)"
+                      % (t_opt, cores, t_opt1), one_thread_value=p.n_terms / t_opt1)
+    return base, opt
 
 
 if __name__ == "__main__":

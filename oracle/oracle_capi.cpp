@@ -22,6 +22,7 @@ struct Problem {
   std::vector<std::unique_ptr<CameraDv>> cameras;
   std::vector<std::unique_ptr<ErrorTerm>> terms;
   Optimizer2 opt;
+  int nextShareGroup = 0;
   bool finalized = false;
   std::string err;
 
@@ -145,8 +146,10 @@ int orc_add_reprojection_batch(void* h, int cam, int spline, int dvQcb, int dvTc
       HomP pt(new HomogeneousMultiplyNode(T_c_p, HomP(new HomogeneousConstantNode(ph))));
       std::unique_ptr<ReprojectionError> e(new ReprojectionError(&y[2 * k], sinv[k], pt, P->cameras[cam].get(), false));
       e->mest.kind = mestKind; e->mest.a = mestParam;
+      e->shareGroup = P->nextShareGroup;
       P->terms.push_back(std::move(e));
     }
+    ++P->nextShareGroup;
   }
   return 0;
   ORC_CATCH(P, -1)
@@ -168,8 +171,10 @@ int orc_add_static_reprojection_batch(void* h, int cam, int nChain, const int* c
       HomP pt(new HomogeneousMultiplyNode(T, HomP(new HomogeneousConstantNode(ph))));
       std::unique_ptr<ReprojectionError> e(new ReprojectionError(&y[2 * k], sinv[k], pt, P->cameras[cam].get(), true));
       e->mest.kind = mestKind; e->mest.a = mestParam;
+      e->shareGroup = P->nextShareGroup;
       P->terms.push_back(std::move(e));
     }
+    ++P->nextShareGroup;
   }
   return 0;
   ORC_CATCH(P, -1)
@@ -478,6 +483,7 @@ int orc_dv_block(void* h, int dv, int* blockIndex, int* columnBase) {
 double orc_evaluate_error(void* h, int nThreads, int useMest, double* eOut) {
   Problem* P = (Problem*)h;
   ORC_TRY(P)
+  for (auto& c : P->cameras) c->sync();   // serially, before any thread reads the camera parameters
   double J = P->opt.solver.evaluateError((size_t)nThreads, useMest != 0);
   if (eOut) std::memcpy(eOut, P->opt.solver.e.data(), sizeof(double) * P->opt.solver.JRows);
   return J;

@@ -99,6 +99,10 @@ struct ErrorTerm {
   int dim;
   int rowBase = 0;
   double squaredError = 0.0;  // raw chi^2 cached by the last evaluateError()
+  // Terms built over the SAME expression nodes (the corners of one image observation share the transformation chain, whose
+  // nodes cache their operands like the reference's do) carry the same non-negative group: the threaded evaluateError
+  // never cuts a group in two, so no node is ever evaluated by two threads.  -1: shares no caching node.
+  int shareGroup = -1;
   MEstimator mest;
   Mat error;       // D x 1
   Mat sqrtInvR;    // D x D
@@ -152,9 +156,9 @@ struct CameraDv {
   Camera cam;
   ParamVectorDv* projDv = nullptr;  // parameters live in the dvs; cam is refreshed from them
   ParamVectorDv* distDv = nullptr;
-  void sync() {
-    cam.proj = projDv->p;
-    if (distDv) for (int i = 0; i < 4; ++i) cam.dist.k[i] = distDv->p[i];
+  void sync() {   // writes only when a parameter changed (after an update): concurrent evaluateError threads only read
+    if (cam.proj != projDv->p) cam.proj = projDv->p;
+    if (distDv) for (int i = 0; i < 4; ++i) if (cam.dist.k[i] != distDv->p[i]) cam.dist.k[i] = distDv->p[i];
   }
 };
 struct ReprojectionError : ErrorTerm {
@@ -366,6 +370,13 @@ struct BlockCholeskySolver {
       size_t per = std::max<size_t>(1, errorTerms.size() / nThreads);
       for (size_t i = 0; i < nThreads; ++i) idx[i + 1] = idx[i] + per;
       idx.back() = errorTerms.size();
+      // the reference cuts contiguous ranges blindly (LinearSystemSolver.cpp:50-78); here a cut moves forward to the next
+      // boundary between share groups (see ErrorTerm::shareGroup)
+      for (size_t i = 1; i < nThreads; ++i) {
+        size_t c = std::max(idx[i], idx[i - 1]);
+        while (c > 0 && c < errorTerms.size() && errorTerms[c]->shareGroup >= 0 && errorTerms[c]->shareGroup == errorTerms[c - 1]->shareGroup) ++c;
+        idx[i] = c;
+      }
       std::vector<std::thread> th;
       for (size_t i = 0; i < nThreads; ++i) th.emplace_back([&, i] { evaluateRange(idx[i], idx[i + 1], useM, &local[i]); });
       for (auto& t : th) t.join();

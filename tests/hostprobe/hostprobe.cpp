@@ -316,3 +316,4 @@ int probe_motion_q(void* h, int which, double* out, int N) {
   return -1;
 }
 }
+#include "cpu_optimised.inc"

@@ -17,7 +17,7 @@ def _load():
     global _L
     if _L is None:
         if not os.path.exists(PROBE_LIB):
-            subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+            subprocess.check_call(["g++", "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wno-unknown-pragmas",
                                    "-o", PROBE_LIB, os.path.join(PROBE_DIR, "hostprobe.cpp")])
         _L = C.CDLL(PROBE_LIB)
         _L.probe_create.restype = C.c_void_p
@@ -141,6 +141,16 @@ class ProbeApi(object):
         c = C.c_double()
         d = self._chk(self.L.probe_term(self.h, C.c_int(t), C.c_int(int(use_mest)), _d(J), _d(e), C.byref(c)))
         return J[:d], e[:d], c.value
+
+    def cpu_optimised(self, use_mest=True, build=True, n_threads=1):
+        """evaluateError (+ buildSystem) of the whole problem on the host with the product's formulation and OpenMP
+        (tests/hostprobe/cpu_optimised.inc).  Returns (J, Cx, rhs); Cx / rhs are None for build=False."""
+        Cx = np.zeros(self.nnz if build else 1)
+        rhs = np.zeros(self.j_cols if build else 1)
+        J = C.c_double()
+        self._chk(self.L.probe_cpu_optimised(self.h, C.c_int(int(use_mest)), C.c_int(int(build)), C.c_int(int(n_threads)), _d(Cx), _d(rhs),
+                                             C.byref(J)))
+        return (J.value, Cx, rhs) if build else (J.value, None, None)
 
     def term_kind(self, t):
         return self.L.probe_term_kind(self.h, C.c_int(t))

@@ -57,3 +57,23 @@ def test_sharding_partitions_terms(small_problem):
     assert np.all(total == 1)
     sizes = [int(f.sum()) for f in flags]
     assert min(sizes) > 0.2 * max(sizes), sizes
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_cpu_optimised_baseline_equals_the_oracle(small_problem, small_oracle, threads):
+    """bench.py's `cpu_optimised` baseline (the product's formulation compiled for the host, OpenMP over work items) must
+    compute what the oracle computes: same cost, same H and rhs (1e-9), on 1 and on 4 threads."""
+    from probe_api import ProbeApi
+    o, _ = small_oracle
+    p = ProbeApi()
+    small_problem["spec"].emit(p)
+    p.finalize()
+    Jo, _ = o.evaluate_error(True)
+    Cp, Ci, Cx, rhs = o.build_system(True)
+    J, Cxp, rhsp = p.cpu_optimised(True, True, threads)
+    assert abs(J - Jo) <= 1e-9 * Jo
+    assert np.abs(Cxp - Cx).max() <= 1e-9 * np.abs(Cx).max()
+    assert np.abs(rhsp - rhs).max() <= 1e-9 * np.abs(rhs).max()
+    assert np.all(Cxp[Cx == 0.0] == 0.0)
+    J2, _, _ = p.cpu_optimised(True, False, threads)
+    assert abs(J2 - Jo) <= 1e-9 * Jo
