@@ -159,6 +159,31 @@ int orc_u_distort(int kind, const double* k, const double* y, double* yd, double
   return 0;
 }
 
+// aslam::calibration::OptimizationProblem (incremental_calibration/src/core/OptimizationProblem.cpp): the design-variable
+// enumeration Optimizer2::initialize walks.  addDesignVariable (:123-137) appends the variable to its group's vector and
+// the group id to _groupsOrdering on first sight; designVariable(idx) (:215-221) resolves idx through getGroupId (:272-292):
+// groups in first-insertion order, insertion order inside a group.  groupIds[i] = group of the i-th addDesignVariable call;
+// order[idx] = insertion index of the variable the problem reports at position idx.
+int orc_u_problem_design_variable_order(int n, const int* groupIds, int* order) {
+  std::vector<int> groupsOrdering;
+  std::map<int, std::vector<int>> designVariables;
+  for (int i = 0; i < n; ++i) {
+    if (!designVariables.count(groupIds[i])) groupsOrdering.push_back(groupIds[i]);
+    designVariables[groupIds[i]].push_back(i);
+  }
+  for (int idx = 0; idx < n; ++idx) {
+    size_t idxRunning = 0;
+    int groupIdRunning = 0;
+    for (int g : groupsOrdering) {
+      const size_t groupSize = designVariables.at(g).size();
+      if (idxRunning + groupSize > (size_t)idx) { groupIdRunning = g; break; }
+      idxRunning += groupSize;
+    }
+    order[idx] = designVariables.at(groupIdRunning)[idx - idxRunning];
+  }
+  return 0;
+}
+
 // ---- the linear fixture of SampleDvAndError.hpp on the oracle's Problem
 // Point2d / DummyDesignVariable<N>: an n-vector with additive update
 int orc_add_vector_dv(void* h, int n, const double* v, int active) {

@@ -411,3 +411,51 @@ def test_spline_pose_kinematics_against_mpmath():
         assert np.abs(J[:, :3] - Dm).max() <= 1e-11 * np.abs(Dm).max(), np.abs(J[:, :3] - Dm).max()
         assert np.abs(Dp - Dm).max() <= 1e-11 * np.abs(Dm).max()
         assert float(mp.norm(w_b)) > 0
+
+
+# ------------------------------------------------------------------------------------------ design-variable order (row A2)
+def test_problem_order_is_group_first_insertion_order(small_problem):
+    """The block indices of the whole path hang on the order in which inc.CalibrationOptimizationProblem reports its
+    design variables (OptimizationProblem.cpp:123-137, 215-221, 272-292).  multical_amd/spec.py orders them in Python
+    (`dv_order`); here the ORACLE restates the reference's container logic from the raw insertion sequence, and both must
+    agree -- on the Multical problem (pose spline in the HELPER group first, calibration parameters interleaved) and on
+    shuffled group sequences."""
+    o = _olib()
+
+    def oracle_order(groups):
+        g = _i32(groups)
+        out = np.zeros(g.size, np.int32)
+        assert o.orc_u_problem_design_variable_order(g.size, _i(g), _i(out)) == 0
+        return out.tolist()
+
+    spec = small_problem["spec"]
+    ins = [i for i, (k, d) in enumerate(spec.ops) if k in ("dv", "spline")]
+    groups = [spec.ops[i][1]["group"] for i in ins]
+    assert len(set(groups)) >= 2 and groups != sorted(groups) and groups != sorted(groups, reverse=True)
+    assert [ins[j] for j in oracle_order(groups)] == spec.dv_order()
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        groups = rng.integers(0, 4, 30).tolist()
+        want = []
+        for g in dict.fromkeys(groups):
+            want += [i for i, x in enumerate(groups) if x == g]
+        assert oracle_order(groups) == want
+    # and the block indices that follow from it: feed the oracle in ITS order, by hand, and compare with spec.emit
+    from oracle_api import OracleApi
+    a = OracleApi()
+    ids = spec.emit(a)
+    a.finalize()
+    groups = [spec.ops[i][1]["group"] for i in ins]
+    blk = 0
+    for j in oracle_order(groups):
+        k, d = spec.ops[ins[j]]
+        if k == "spline":
+            first = a.spline_first_dv(ids[ins[j]][1])
+            n = d["coeffs"].shape[1]
+            if d["active"]:
+                assert [a.dv_block(first + c)[0] for c in range(n)] == list(range(blk, blk + n))
+                blk += n
+        elif d["active"] and not (d["kind"] == 7 and not np.any(d.get("pattern", 1))):
+            assert a.dv_block(ids[ins[j]])[0] == blk, (j, k)
+            blk += 1
+    assert blk == a.n_blocks
