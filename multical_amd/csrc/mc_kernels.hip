@@ -462,11 +462,16 @@ __device__ __forceinline__ int b_pose_first_col(const ImuBatchView& b) { return 
 //   phase 1  thread = term: closed-form residual + Jacobian into a *compact* LDS row
 //            [ 6 live pose-coefficient blocks (36) | the chunk's other columns (G) | residual ], plus beta0 = position
 //            of the live window inside the chunk's coefficient range
-//   phase 2  thread = Hessian entry of the chunk window: gathers sum_k J_k[:,a] J_k[:,b] over the terms whose live
-//            window covers both columns (terms are time sorted, so those are a contiguous run) and issues ONE fp64
-//            atomic per entry; entries are enumerated down the CCS columns so a wave's adds are contiguous runs.
-// Compared with one group per footprint this cuts the atomics by the number of terms that share a window and keeps
-// every lane busy in both phases.
+//   phase 2  lane = 6 x 6 tile of the window's coefficient band (one block pair), then 6 x 4 tile of coefficient x other
+//            columns: it walks the run of terms whose live window covers the tile (terms are time sorted, so that is
+//            a contiguous run) and keeps the tile in registers -- 12 / 10 LDS values per 36 / 24 multiply-adds, where
+//            one lane per entry loads 2 per multiply-add and is bound by LDS bandwidth.  The tiles are turned through
+//            a small per-wave LDS strip so that a wave's fp64 atomics go to consecutive addresses (ONE atomic per
+//            entry and chunk).  The few other x other entries stay one per lane.
+//            The fp64 matrix cores were tried for this Gram (16 x 16 window tiles, operands gathered from the compact
+//            rows): v_mfma_f64_16x16x4 has the same peak as the vector unit on this part and the band fills only half
+//            of each tile, so it ran 2-3x slower than the vector gathers.
+// Compared with one group per footprint this cuts the atomics by the number of terms that share a window.
 struct StreamDims { int maxT, maxNb, maxNob, maxG, ld, maxTab; };
 template <class View> struct StreamBatch {
   View v;
@@ -553,6 +558,9 @@ template <> struct StreamTraits<ImuSmBatchView> {
   }
 };
 
+#ifndef MC_GATHER_UNROLL
+#define MC_GATHER_UNROLL 1
+#endif
 #ifndef MC_STREAM_OCC
 #define MC_STREAM_OCC 1
 #endif
@@ -586,6 +594,7 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
   const int* oh = oo_slot + nob * nob;
   const int* ocolblk = oh + nob;
   const int* oinfo = ocolblk + G;   // nob x (block index, local column start, global column base), staged with the table
+  int* atab = tab + dm.maxTab;      // (G, nb) coefficient x other addresses, filled below
   __shared__ double red[4];
   constexpr bool build = BUILD;
   if (build) {
@@ -633,106 +642,181 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
     dc.Jpart[jpart_base + blockIdx.x] = Js;
   }
   if (!build) return;
-  // Terms are time sorted and share one time offset, so beta0 is non-decreasing over the chunk and the terms of
-  // segment s are exactly the run [rlo[s], rhi[s]) (a failed term inside a run has an all-zero row).  A violation
-  // would silently drop products, so it is checked and reported.
+  // Terms are time sorted and share one time offset, so beta0 is non-decreasing over the chunk and the terms whose
+  // first live block is >= s are a suffix [fge[s], T) (a failed term inside has an all-zero row).  A violation would
+  // silently drop products, so it is checked and reported.
   if (tid > 0 && tid < T && beta0[tid] >= 0 && beta0[tid - 1] >= 0 && beta0[tid] < beta0[tid - 1]) atomicOr(dc.status, STATUS_INTERNAL);
   if (MC_MODE(dc) == 3) return;
-  const int ecol = 36 + G;
-  (void)ecol;
-  const int rstride = D * ld;
-  // ---- phase 2 (i): coefficient band.  One thread per (block column bj, row rho of the 6 blocks ending at the
-  // diagonal): it accumulates the 6 entries of that row inside block column bj, so every J element it loads feeds
-  // 6 multiply-adds; for a fixed column the 36 threads of a block column write 36 consecutive values.
-  for (int idx = tid; idx < nb * 36; idx += 256) {
-    const int bj = idx / 36, rho = idx - 36 * bj;
-    const int d = 5 - rho / 6, ra = rho % 6;
-    const int bi = bj - d;
-    if (bi < 0) continue;
-    const int slot = band_slot[bj * 6 + d];
-    if (slot < 0) continue;
-    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int sg = max(0, bj - 5); sg <= bi; ++sg) {
-      const int kb = rhi[sg], ka = min(rlo[sg], kb);
-      const double* p1 = rows + (size_t)ka * rstride + (bi - sg) * 6 + ra;
-      const double* p2 = rows + (size_t)ka * rstride + (bj - sg) * 6;
-      for (int k = ka; k < kb; ++k, p1 += rstride, p2 += rstride) {
-#pragma unroll
-        for (int r = 0; r < D; ++r) {
-          const double xv = p1[r * ld];
-          const double2* q = reinterpret_cast<const double2*>(p2 + r * ld);   // 16-byte aligned: ld and 6 (bj - sg) are even
-          const double2 y01 = q[0], y23 = q[1], y45 = q[2];
-          acc[0] += xv * y01.x; acc[1] += xv * y01.y; acc[2] += xv * y23.x;
-          acc[3] += xv * y23.y; acc[4] += xv * y45.x; acc[5] += xv * y45.y;
-        }
-      }
-    }
-    if (MC_MODE(dc) != 1) { if (acc[0] + acc[5] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
-    const int h = hcol[bj];
-#pragma unroll
-    for (int cb = 0; cb < 6; ++cb)
-      if (acc[cb] != 0.0 && !(d == 0 && ra > cb)) atomic_add_f64(dc.Cx + slot + cb * h + (cb * (cb + 1)) / 2 + ra, acc[cb]);
+  int* fge = rhi;
+  if (tid <= nb) {
+    int m = T;
+    for (int s = tid; s <= nb; ++s) m = min(m, rlo[s]);
+    fge[tid] = m;
   }
-  MC_MARK(pslot + 2);   // band gather + flush
-  // ---- phase 2 (ii): coefficient x other columns (and the coefficient part of rhs: other column G = residual).
-  // One thread per (coefficient column, tile of GT other columns).
-  constexpr int GT = 7;
-  const int npc = 6 * nb, ngt = (G + 1 + GT - 1) / GT;
-  for (int idx = tid; idx < ngt * npc; idx += 256) {
-    const int gt = idx / npc, pc = idx - gt * npc;
-    const int bi = pc / 6, ra = pc - 6 * bi;
-    const int g0 = gt * GT;
-    double acc[GT];
+  __syncthreads();
+  MC_MARK(pslot + 2);   // run table
+  // ---- phase 2: the chunk's Gram, register blocked.  A lane owns a 6 x 6 (band) or 6 x 4 (coefficient x other) tile
+  // of the window's Hessian and walks the run of terms whose live window covers it: 12 (10) LDS values feed 36 (24)
+  // multiply-adds.  The tiles are then turned through a per-wave LDS strip so that the fp64 adds of a wave go to
+  // consecutive addresses: a lane's 6 values of one Hessian column are consecutive in the CCS array, and so are those
+  // of the next lane (the rows of a column are ordered by block), hence element e of the strip is address base + e.
+  __shared__ double wstrip[4][32 * 6];
+  const int lane = tid & 63, wave = tid >> 6;
+  double* strip = wstrip[wave];
+  const int rstride = D * ld;
+  // turn6: every lane hands in 6 values; emit(p, v) receives element e = 64 p + lane (p = 0..5) of the wave's 384 values
+  // (element 6 l + i = value i of lane l).  Half a wave at a time through the 32 x 6 strip; LDS accesses of one wave
+  // execute in program order, the barriers only pin the compiler's schedule.
+  auto turn6 = [&](const double (&v)[6], auto&& emit) {
 #pragma unroll
-    for (int j = 0; j < GT; ++j) acc[j] = 0.0;
-    for (int sg = max(0, bi - 5); sg <= bi; ++sg) {
-      const int kb = rhi[sg], ka = min(rlo[sg], kb);
-      const double* p1 = rows + (size_t)ka * rstride + (bi - sg) * 6 + ra;
-      const double* p2 = rows + (size_t)ka * rstride + 36 + g0;
-      for (int k = ka; k < kb; ++k, p1 += rstride, p2 += rstride) {
+    for (int h = 0; h < 2; ++h) {
+      if ((lane >> 5) == h) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) strip[(lane & 31) * 6 + i] = v[i];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int p = 0; p < 3; ++p) emit(3 * h + p, strip[64 * p + lane]);
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  // address table of the coefficient x other entries: atab[g nb + bi] = value index of (row 0 of block bi, other column
+  // g) when the other block is the column, -2 - (index of (other column's component, row 0 of block bi)) when the
+  // coefficient block is the column, -1 when the pair is not in the pattern
+  for (int i = tid; i < G * nb; i += 256) {
+    const int g = i / nb, bi = i - g * nb;
+    const int o = ocolblk[g], sc = g - oinfo[3 * o + 1];
+    const int slot = arrow_slot[o * nb + bi];
+    int a = -1;
+    if (slot >= 0) a = oinfo[3 * o] < pb + bi ? -2 - (slot + sc) : slot + sc * oh[o] + (sc * (sc + 1)) / 2;
+    atab[i] = a;
+  }
+  // (i) coefficient band: task = (block column bj, block row bi = bj - d), ordered down the CCS column (d = 5 .. 0)
+  const int nband = 6 * nb;
+  for (int base = 0; base < nband; base += 256) {
+    const int t = base + tid;
+    const int bj = t / 6, d = 5 - (t - 6 * bj), bi = bj - d;
+    double acc[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[i][j] = 0.0;
+    if (t < nband && bi >= 0 && band_slot[bj * 6 + d] >= 0) {
+      const int k1 = fge[bi + 1];
+#pragma unroll MC_GATHER_UNROLL
+      for (int k = fge[max(0, bj - 5)]; k < k1; ++k) {
+        const int o = bi - beta0[k];
+        if ((unsigned)o > (unsigned)(5 - d)) continue;   // a failed term (all-zero row)
+        const double* px = rows + (size_t)k * rstride + 6 * o;
 #pragma unroll
         for (int r = 0; r < D; ++r) {
-          const double xv = p1[r * ld];
+          const double2* qx = reinterpret_cast<const double2*>(px + r * ld);   // 16-byte aligned: ld and 6 o are even
+          const double2* qy = reinterpret_cast<const double2*>(px + r * ld + 6 * d);
+          const double2 x01 = qx[0], x23 = qx[1], x45 = qx[2], y01 = qy[0], y23 = qy[1], y45 = qy[2];
+          const double xv[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+          const double yv[6] = {y01.x, y01.y, y23.x, y23.y, y45.x, y45.y};
 #pragma unroll
-          for (int j = 0; j < GT; ++j) acc[j] += xv * p2[r * ld + j];   // columns past G read the zeroed padding of the row
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] += xv[i] * yv[j];
         }
       }
     }
-    if (MC_MODE(dc) != 1) { if (acc[0] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    if (MC_MODE(dc) != 1) { if (acc[0][0] + acc[5][5] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    // element e of the wave belongs to task tb + e / 6, row e % 6; its address less the column part is the same for
+    // the 6 columns
+    const int tb = base + 64 * wave;
+    int eaddr[6], eh[6], era[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int e = 64 * p + lane, t2 = tb + e / 6, ra = e % 6;
+      const int bj2 = t2 / 6, d2 = 5 - (t2 - 6 * bj2);
+      int slot = -1;
+      if (t2 < nband && bj2 - d2 >= 0) slot = band_slot[bj2 * 6 + d2];
+      eaddr[p] = slot >= 0 ? slot + ra : -1;
+      eh[p] = t2 < nband ? hcol[bj2] : 0;
+      era[p] = d2 == 0 ? ra : -1;   // diagonal block: rows below the diagonal are not stored
+    }
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      const double v6[6] = {acc[0][cc], acc[1][cc], acc[2][cc], acc[3][cc], acc[4][cc], acc[5][cc]};
+      turn6(v6, [&](int p, double v) {
+        if (v != 0.0 && eaddr[p] >= 0 && era[p] <= cc) atomic_add_f64(dc.Cx + eaddr[p] + cc * eh[p] + (cc * (cc + 1)) / 2, v);
+      });
+    }
+  }
+  MC_MARK(pslot + 3);   // band
+  __syncthreads();      // atab
+  // (ii) coefficient x other columns (and the coefficient part of rhs: other column G = residual).
+  // task = (tile of 4 other columns, coefficient block bi), consecutive lanes = consecutive blocks
+  constexpr int GT = 4;
+  const int ngt = (G + 1 + GT - 1) / GT;
+  const int narrow = nb > 0 ? ngt * nb : 0;
+  for (int base = 0; base < narrow; base += 256) {
+    const int t = base + tid;
+    const int gt = t / max(nb, 1), bi = t - gt * nb;
+    double acc[6][GT];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < GT; ++j) acc[i][j] = 0.0;
+    if (t < narrow) {
+      const int k1 = fge[bi + 1];
+#pragma unroll MC_GATHER_UNROLL
+      for (int k = fge[max(0, bi - 5)]; k < k1; ++k) {
+        const int o = bi - beta0[k];
+        if ((unsigned)o > 5u) continue;
+        const double* px = rows + (size_t)k * rstride;
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+          const double2* qx = reinterpret_cast<const double2*>(px + r * ld + 6 * o);
+          const double2* qy = reinterpret_cast<const double2*>(px + r * ld + 36 + GT * gt);   // columns past G: zeroed padding
+          const double2 x01 = qx[0], x23 = qx[1], x45 = qx[2], y01 = qy[0], y23 = qy[1];
+          const double xv[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+          const double yv[GT] = {y01.x, y01.y, y23.x, y23.y};
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < GT; ++j) acc[i][j] += xv[i] * yv[j];
+        }
+      }
+    }
+    if (MC_MODE(dc) != 1) { if (acc[0][0] + acc[5][GT - 1] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    const int tb = base + 64 * wave;
+    int eq[6], eg[6], ebi[6], era[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int e = 64 * p + lane, t2 = tb + e / 6;
+      const int gt2 = t2 / max(nb, 1);
+      era[p] = e % 6; ebi[p] = t2 - gt2 * nb; eg[p] = t2 < narrow ? GT * gt2 : G + 1; eq[p] = GT * gt2 * nb + ebi[p];
+    }
+    const int rhs0 = b_pose_first_col(b) + 6 * ch.pose_lo;
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
-      const int g = g0 + j;
-      if (g > G || acc[j] == 0.0) continue;
-      if (g == G) { atomic_add_f64(dc.rhs + b_pose_first_col(b) + 6 * (ch.pose_lo + bi) + ra, -acc[j]); continue; }
-      const int o = ocolblk[g], sc = g - oinfo[3 * o + 1];
-      const int slot = arrow_slot[o * nb + bi];
-      if (slot < 0) continue;
-      if (oinfo[3 * o] < pb + bi) atomic_add_f64(dc.Cx + slot + ra * hcol[bi] + (ra * (ra + 1)) / 2 + sc, acc[j]);   // column = coefficient
-      else atomic_add_f64(dc.Cx + slot + sc * oh[o] + (sc * (sc + 1)) / 2 + ra, acc[j]);                          // column = other
+      const double v6[6] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], acc[5][j]};
+      turn6(v6, [&](int p, double v) {
+        const int g = eg[p] + j;
+        if (v == 0.0 || g > G) return;
+        if (g == G) { atomic_add_f64(dc.rhs + rhs0 + 6 * ebi[p] + era[p], -v); return; }
+        const int a = atab[eq[p] + j * nb];
+        if (a >= 0) atomic_add_f64(dc.Cx + a + era[p], v);                                                                  // column = other
+        else if (a < -1) atomic_add_f64(dc.Cx + (-2 - a) + era[p] * hcol[ebi[p]] + (era[p] * (era[p] + 1)) / 2, v);         // column = coefficient
+      });
     }
   }
-  MC_MARK(pslot + 3);   // coefficient x other gather + flush
-  // ---- phase 2 (iii): other x other (upper triangle) and the other part of rhs
-  const int G1 = G + 1;
-  for (int idx = tid; idx < G1 * G1; idx += 256) {
-    const int g2 = idx / G1, g1 = idx - g2 * G1;
-    if (g1 > g2 || g1 == G) continue;
-    double acc = 0.0;
-    for (int k = 0; k < T; ++k) {
-      const double* row = rows + (size_t)k * rstride;
-#pragma unroll
-      for (int r = 0; r < D; ++r) acc += row[r * ld + 36 + g1] * row[r * ld + 36 + g2];
-    }
-    if (acc == 0.0 || MC_MODE(dc) != 1) continue;
+  MC_MARK(pslot + 4);   // coefficient x other
+  // (iii) other x other (upper triangle) and the other part of rhs
+  auto oo_flush = [&](int g1, int g2, double acc) {
+    if (g1 > g2 || g1 >= G || g2 > G || acc == 0.0) return;
     const int o1 = ocolblk[g1], s1 = g1 - oinfo[3 * o1 + 1];
     // entries between two global design variables (extrinsics, time offset, target poses, gravity ...) are written by every
     // chunk of the stream: they go to this workgroup's replica (folded into Cx / rhs by k_rep_reduce)
     const int gb1 = dc.rep ? dc.gcb[oinfo[3 * o1]] : -1;
-    if (g2 == G) { atomic_add_f64(gb1 >= 0 ? rep_rhs_entry(dc, gb1 + s1) : dc.rhs + oinfo[3 * o1 + 2] + s1, -acc); continue; }
+    if (g2 == G) { atomic_add_f64(gb1 >= 0 ? rep_rhs_entry(dc, gb1 + s1) : dc.rhs + oinfo[3 * o1 + 2] + s1, -acc); return; }
     const int o2 = ocolblk[g2], s2 = g2 - oinfo[3 * o2 + 1];
     if (gb1 >= 0) {
       const int gb2 = dc.gcb[oinfo[3 * o2]];
-      if (gb2 >= 0) { atomic_add_f64(rep_entry(dc, min(gb1 + s1, gb2 + s2), max(gb1 + s1, gb2 + s2)), acc); continue; }
+      if (gb2 >= 0) { atomic_add_f64(rep_entry(dc, min(gb1 + s1, gb2 + s2), max(gb1 + s1, gb2 + s2)), acc); return; }
     }
     if (o1 == o2) {
       int slot = oo_slot[o1 * nob + o1];
@@ -744,8 +828,19 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
       int slot = oo_slot[o2 * nob + o1];
       if (slot >= 0) atomic_add_f64(dc.Cx + slot + s1 * oh[o1] + (s1 * (s1 + 1)) / 2 + s2, acc);
     }
+  };
+  const int G1 = G + 1;
+  for (int idx = tid; idx < G1 * G1; idx += 256) {
+    const int g2 = idx / G1, g1 = idx - g2 * G1;
+    if (g1 > g2 || g1 == G) continue;
+    double acc = 0.0;
+    const double* row = rows + 36;
+#pragma unroll 8
+    for (int k = 0; k < T * D; ++k, row += ld) acc += row[g1] * row[g2];   // unrolled: independent LDS reads in flight
+    if (MC_MODE(dc) != 1) { if (acc == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+    oo_flush(g1, g2, acc);
   }
-  MC_MARK(pslot + 4);   // other x other
+  MC_MARK(pslot + 5);   // other x other
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1706,9 +1801,9 @@ void mc_context::uploadStructure() {
       L.n_items = (int)chunks[l].size();
       L.n_jpart = L.n_items;
       StreamDims& dm = L.dims;
-      dm.ld = (36 + ((dm.maxG + 1 + 6) / 7) * 7 + 1) & ~1;   // other columns + residual padded to whole 7-column tiles; even (16-byte aligned pairs)
+      dm.ld = 36 + ((dm.maxG + 1 + 3) / 4) * 4;   // 36 live coefficient columns + (other columns + residual) padded to whole 4-column tiles
       const int dim = l == LAUNCH_LIDAR ? 1 : 3;
-      size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + dm.maxTab + 4;
+      size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + dm.maxTab + (size_t)dm.maxG * dm.maxNb + 4;
       L.lds_bytes = (int)((size_t)dm.maxT * dim * dm.ld * sizeof(double) + ints * sizeof(int) + 16);
       if (L.lds_bytes > 150 * 1024) throw std::runtime_error("chunk tile exceeds the LDS budget");
       if (L.lds_bytes > 64 * 1024) {

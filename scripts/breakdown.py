@@ -27,12 +27,13 @@ print("total: " + "  ".join("mode%d %.3f" % (m, float(res[m].sum())) for m in re
 
 if 'timing' not in os.environ.get('MULTICAL_HIP_LIB', ''):
     sys.exit(0)
-ph = api.phase_cycles(True, 1)
 names = {0: "stage record", 1: "project+z", 2: "wait waves", 3: "mfma gram", 4: "G->T->M", 5: "board flush", 6: "image flush",
-         8: "lidar eval", 9: "lidar wait", 10: "lidar band", 11: "lidar arrow", 12: "lidar oo",
-         16: "imu eval", 17: "imu wait", 18: "imu band", 19: "imu arrow", 20: "imu oo"}
+         8: "lidar eval", 9: "lidar wait", 10: "lidar runs", 11: "lidar band", 12: "lidar arrow", 13: "lidar oo",
+         16: "imu eval", 17: "imu wait", 18: "imu runs", 19: "imu band", 20: "imu arrow", 21: "imu oo"}
 nwg = {0: info[0][3], 8: info[3][3], 16: info[2][3]}
-for base in (0, 8, 16):
-    tot = ph[base:base + 8].sum()
-    print("phases (%s), cycles per workgroup: " % ("k_reproj" if base == 0 else names[base].split()[0]) +
-          "  ".join("%s %.0f (%.0f%%)" % (names[i], ph[i] / max(1, nwg[base]), 100 * ph[i] / max(1.0, tot)) for i in range(base, base + 8) if i in names))
+for pmode in (int(m) for m in os.environ.get('MC_PHASE_MODES', '1').split(',')):
+    ph = api.phase_cycles(True, pmode)
+    for base in (0, 8, 16):
+        tot = ph[base:base + 8].sum()
+        print("mode %d phases (%s), cycles per workgroup: " % (pmode, "k_reproj" if base == 0 else names[base].split()[0]) +
+              "  ".join("%s %.0f (%.0f%%)" % (names[i], ph[i] / max(1, nwg[base]), 100 * ph[i] / max(1.0, tot)) for i in range(base, base + 8) if i in names))
