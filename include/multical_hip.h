@@ -77,7 +77,8 @@ int mc_add_camera(mc_context* ctx, int projection_model, int distortion_model, i
 
 /* Error-term batches.  Terms are numbered in call order (row base = running sum of dimensions,
  * Optimizer2.cpp:130-135).  sqrt_inv_r[k] is the scalar s with sqrtInvR = s*I (Multical uses
- * isotropic covariances throughout).  All return 0 or a negative error. */
+ * isotropic covariances throughout; a general sqrtInvR follows the batch with mc_set_last_batch_sqrt_inv_r).
+ * All return 0 or a negative error. */
 
 /* SimpleReprojectionError over T_c_b * T_w_b(t + d)^-1 * T_p_w^-1 * p  (sensors_and_targets.py:556-630;
  * aslam_cv_error_terms/.../SimpleReprojectionError.hpp:43-64; time-offset node
@@ -141,6 +142,15 @@ int mc_add_lidar_batch(mc_context* ctx, int pose_spline, int dv_time_offset, int
                        const double* t, const double* dir /* [n,3] unit */, const double* range,
                        const double* sqrt_inv_r, const int* dv_q_p_w, const int* dv_t_p_w, double time_padding,
                        int mest_kind, double mest_param);
+/* ErrorTermFs<D>::setSqrtInvR for the terms of the batch added last (aslam_backend/include/aslam/backend/ErrorTerm.hpp:246,
+ * implementation/ErrorTerm.hpp:96-192): S is [n, dim, dim] row major, one general sqrtInvR per term (invR = S S^T; the weighted
+ * error is sqrt(w) S^T e, the weighted Jacobian sqrt(w) S^T J, chi2 = e^T invR e); it replaces the scalars given with the batch.
+ * dim and n must be the batch's error dimension and term count.  Not for the motion / transformation terms, which carry their
+ * own weighting.  A lowering reads S from the term's sqrtInvR(); callers that hold invR use mc_compute_matrix_sqrt. */
+int mc_set_last_batch_sqrt_inv_r(mc_context* ctx, int dim, int n, const double* S);
+/* sm::eigen::computeMatrixSqrt (Schweizer-Messer/sm_eigen/include/sm/eigen/matrix_sqrt.hpp:21-40), what ErrorTermFs<D>::setInvR
+ * applies to invR: S = P^T L sqrt(D) of the pivoted LDL^T, A = S S^T.  A and S are n x n row major, n <= 16.  Host only. */
+int mc_compute_matrix_sqrt(int n, const double* A, double* S);
 /* BSplineMotionError (aslam_splines/include/aslam/backend/implementation/BSplineMotionError.hpp:28-166).  W is dim x dim. */
 int mc_add_motion_term(mc_context* ctx, int spline, const double* W, int error_term_order);
 

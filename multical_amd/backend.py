@@ -155,6 +155,25 @@ class HipApi(object):
         W = _f64(W)
         self._chk(self.lib.mc_add_motion_term(self.ctx, spline, _dp(W), order))
 
+    def compute_matrix_sqrt(self, A):
+        """sm::eigen::computeMatrixSqrt: S with A = S S^T (what ErrorTermFs.setInvR applies to invR)"""
+        A = _f64(A)
+        S = np.empty_like(A)
+        if self.lib.mc_compute_matrix_sqrt(A.shape[0], _dp(A), _dp(S)) != 0:
+            raise ValueError("mc_compute_matrix_sqrt: bad size")
+        return S
+
+    def set_last_batch_sqrt_inv_r(self, S):
+        """general per-term sqrtInvR [n, D, D] for the batch added last (ErrorTermFs.setSqrtInvR)"""
+        S = _f64(S)
+        assert S.ndim == 3 and S.shape[1] == S.shape[2]
+        self._chk(self.lib.mc_set_last_batch_sqrt_inv_r(self.ctx, S.shape[1], S.shape[0], _dp(S)))
+
+    def set_last_batch_inv_r(self, invR):
+        """ErrorTermFs.setInvR per term: invR [n, D, D]"""
+        invR = _f64(invR)
+        self.set_last_batch_sqrt_inv_r(np.stack([self.compute_matrix_sqrt(R) for R in invR]))
+
     def set_shard(self, rank, world):
         self._chk(self.lib.mc_set_shard(self.ctx, rank, world))
 

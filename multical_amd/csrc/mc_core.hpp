@@ -82,6 +82,7 @@ struct Batch {
   double w_t = 1.0, w_r = 1.0;   // ErrorTermTransformation: translation / rotation weights (diagonal invR)
   // per-term / per-observation host arrays
   std::vector<double> t, y, p, sinv, meas, range;
+  std::vector<double> S;   // optional general sqrtInvR, n_terms x dim x dim row major (mc_set_last_batch_sqrt_inv_r)
   std::vector<int> obs_first, obs_dv_q, obs_dv_t, term_dv_q, term_dv_t, term_obs;
   std::vector<int> chain_q, chain_t;
   // motion term

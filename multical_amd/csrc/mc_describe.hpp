@@ -183,6 +183,18 @@ inline void describeLidar(Problem& P, int spline, int dv_toff, int dv_q_lb, int 
 // BSplineMotionError: Q = sum_seg M^T (W (x) V^(d)) M scattered into (seg+i, seg+j) blocks
 // (BSP/src/BSpline.cpp:1276-1302, 1483-1548, 1585-1622).  Because M only mixes the S basis functions, block
 // (i, j) of a segment's Q equals  (B^T V_d B)(i, j) * W  with B the segment's S x S basis matrix.
+// ErrorTermFs<D>::setSqrtInvR for the terms of the batch added last (general, per term)
+inline void describeSqrtInvR(Problem& P, int dim, int n, const double* S) {
+  requireOpen(P);
+  if (P.batches.empty()) throw std::invalid_argument("no error-term batch has been added");
+  Batch& b = P.batches.back();
+  if (b.kind == KIND_MOTION || b.kind == KIND_TRANSFORMATION)
+    throw std::invalid_argument("this term type carries its own weighting (W / weightRotation, weightTranslation)");
+  if (dim != b.dim || n != b.n_terms) throw std::invalid_argument("The covariance matrix does not match the size of the error");
+  if (!S) throw std::invalid_argument("S is NULL");
+  if (dim == 1) b.sinv.assign(S, S + n);
+  else b.S.assign(S, S + (size_t)n * dim * dim);
+}
 inline void describeMotion(Problem& P, int spline, const double* W, int order) {
   requireOpen(P);
   if (spline < 0 || spline >= (int)P.splines.size()) throw std::invalid_argument("spline id out of range");

@@ -1417,7 +1417,7 @@ template <class T> struct DevBuf {
 
 // Per-batch device arrays (the SoA term records).
 struct DevBatch {
-  DevBuf<double> t, y, p, sinv, meas, range, Qband;
+  DevBuf<double> t, y, p, sinv, S, meas, range, Qband;
   DevBuf<int> obs_first, obs_q_off, obs_t_off, term_q_off, term_t_off, term_obs, slot, order, term_lo, term_nbuf;
 };
 
@@ -1673,6 +1673,7 @@ void mc_context::uploadStructure() {
       }
     }
     d->sinv.upload(b.sinv);
+    if (!b.S.empty()) d->S.upload(b.S);
     if (b.kind == KIND_REPROJ) {
       d->t.upload(b.t); d->y.upload(b.y); d->p.upload(b.p);
       d->obs_first.upload(b.obs_first); d->obs_q_off.upload(offs(b.obs_dv_q)); d->obs_t_off.upload(offs(b.obs_dv_t));
@@ -1683,7 +1684,7 @@ void mc_context::uploadStructure() {
       v.coef_scale = 1.0; v.qpw_scale = 1.0; v.tpw_scale = 1.0;
       if (!b.obs_dv_q.empty()) { v.qpw_scale = P.dvs[b.obs_dv_q[0]].scaling; v.tpw_scale = P.dvs[b.obs_dv_t[0]].scaling; }
       v.obs_time = d->t.p; v.obs_first = d->obs_first.p; v.obs_qpw_off = d->obs_q_off.p; v.obs_tpw_off = d->obs_t_off.p;
-      v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p;
+      v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p; v.S = b.S.empty() ? nullptr : d->S.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
       v.row_base = b.row_base; v.term_base_global = term_base;
       rviews.push_back(v);
@@ -1709,7 +1710,7 @@ void mc_context::uploadStructure() {
       v.bias_dv = P.dvRef(b.dv[0]); v.g = P.dvRef(b.dv[1]); v.q_ib = P.dvRef(b.dv[2]); v.r_b = P.dvRef(b.dv[3]);
       v.g_is_direction = P.dvs[b.dv[1]].kind == DV_EUCLIDEAN_DIRECTION ? 1 : 0;
       v.pose_scale = 1.0; v.bias_scale = b.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
-      v.t = d->t.p; v.meas = d->meas.p; v.sinv = d->sinv.p;
+      v.t = d->t.p; v.meas = d->meas.p; v.sinv = d->sinv.p; v.S = b.S.empty() ? nullptr : d->S.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.is_accel = b.kind == KIND_ACCEL_SM ? 1 : 0;
       v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
       v.M = P.dvRef(b.dv[4]); v.M_mask = P.dvs[b.dv[4]].mask;
@@ -1727,7 +1728,7 @@ void mc_context::uploadStructure() {
       v.bias_dv = P.dvRef(b.dv[0]); v.g = P.dvRef(b.dv[1]); v.q_ib = P.dvRef(b.dv[2]); v.r_b = P.dvRef(b.dv[3]);
       v.g_is_direction = (b.dv[1] >= 0 && P.dvs[b.dv[1]].kind == DV_EUCLIDEAN_DIRECTION) ? 1 : 0;
       v.pose_scale = 1.0; v.bias_scale = b.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
-      v.t = d->t.p; v.meas = d->meas.p; v.sinv = d->sinv.p;
+      v.t = d->t.p; v.meas = d->meas.p; v.sinv = d->sinv.p; v.S = b.S.empty() ? nullptr : d->S.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.is_accel = b.kind == KIND_ACCEL ? 1 : 0;
       v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
       sb.order = d->order.p; sb.term_lo = d->term_lo.p; sb.term_nbuf = d->term_nbuf.p;
@@ -1736,7 +1737,7 @@ void mc_context::uploadStructure() {
       d->p.upload(b.p); d->meas.upload(b.meas);
       GyroPriorBatchView v;
       v.q = P.dvRef(b.dv[0]); v.bias = P.dvRef(b.dv[1]);
-      v.w_pred = d->p.p; v.meas = d->meas.p; v.sinv = d->sinv.p;
+      v.w_pred = d->p.p; v.meas = d->meas.p; v.sinv = d->sinv.p; v.S = b.S.empty() ? nullptr : d->S.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_terms = b.n_terms; v.row_base = b.row_base; v.term_base_global = term_base;
       gviews.push_back(v);
     } else if (b.kind == KIND_TRANSFORMATION) {
@@ -1760,7 +1761,7 @@ void mc_context::uploadStructure() {
       v.proj_scale = P.dvs[P.cams[b.cam].dv_proj].scaling;
       v.dist_scale = P.cams[b.cam].dv_dist >= 0 ? P.dvs[P.cams[b.cam].dv_dist].scaling : 1.0;
       v.obs_first = d->obs_first.p; v.obs_qtc_off = d->obs_q_off.p; v.obs_ttc_off = d->obs_t_off.p; v.term_obs = d->term_obs.p;
-      v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p;
+      v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p; v.S = b.S.empty() ? nullptr : d->S.p;
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
       v.row_base = b.row_base; v.term_base_global = term_base;
       sviews.push_back(v);
@@ -2133,6 +2134,11 @@ int mc_add_lidar_batch(mc_context* ctx, int pose_spline, int dv_time_offset, int
 }
 int mc_add_motion_term(mc_context* ctx, int spline, const double* W, int error_term_order) {
   MC_TRY describeMotion(ctx->P, spline, W, error_term_order);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_set_last_batch_sqrt_inv_r(mc_context* ctx, int dim, int n, const double* S) {
+  MC_TRY describeSqrtInvR(ctx->P, dim, n, S);
   return 0;
   MC_CATCH(ctx, -1)
 }

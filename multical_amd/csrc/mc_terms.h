@@ -93,6 +93,18 @@ MC_HD void load_rigid(const double* x, int qoff, int toff, Rigid& T) {
 // aslam_splines/src/BSplineExpressions.cpp:495-544) -- every corner of one image shares the w_i, which
 // is what lets the kernel reduce a 19x19 core per image instead of an 85x85 block matrix per corner.
 enum { F1_CORE = 19 };
+// General sqrtInvR of ErrorTermFs<D> (aslam_backend/include/aslam/backend/implementation/ErrorTerm.hpp:96-192):
+// weighted error S^T e, weighted Jacobian S^T J, chi2 = e^T (S S^T) e.  S is row major.
+MC_HD void sinv_mix2(const double* S, double& a0, double& a1) {
+  const double t0 = S[0] * a0 + S[2] * a1, t1 = S[1] * a0 + S[3] * a1;
+  a0 = t0; a1 = t1;
+}
+MC_HD void sinv_mix3(const double* S, double* a, int stride) {
+  const double a0 = a[0], a1 = a[stride], a2 = a[2 * stride];
+  a[0] = S[0] * a0 + S[3] * a1 + S[6] * a2;
+  a[stride] = S[1] * a0 + S[4] * a1 + S[7] * a2;
+  a[2 * stride] = S[2] * a0 + S[5] * a1 + S[8] * a2;
+}
 enum { F1_ROLE_COEF = 0, F1_ROLE_QCB = 1, F1_ROLE_TCB = 2, F1_ROLE_QPW = 3, F1_ROLE_TPW = 4, F1_ROLE_TOFF = 5 };
 struct ReprojBatchView {
   CameraView cam;
@@ -106,6 +118,7 @@ struct ReprojBatchView {
   const double* y;
   const double* p;
   const double* sinv;
+  const double* S = nullptr;   // optional general sqrtInvR, n x D x D row major (then sinv is not used)
   int mest; double mest_a;
   int n_obs, n_terms;
   int row_base;   // row base of term 0 of this batch
@@ -159,7 +172,13 @@ MC_HD void f1_project(const ReprojBatchView& b, const double* x, const F1Common&
   (void)x;
   project<EQUI>(b.cam.model, b.cam.dist, cm.pp, cm.dk, pc, kp, wantJ ? Jc : nullptr);
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
-  double s = b.sinv[k];
+  double s;
+  if (b.S) {   // general sqrtInvR: mix the residual and the two rows of the projection Jacobian once, everything below is linear in them
+    const double* S = b.S + 4 * (size_t)k;
+    sinv_mix2(S, e0, e1);
+    if (wantJ) { sinv_mix2(S, Jc[0], Jc[3]); sinv_mix2(S, Jc[1], Jc[4]); sinv_mix2(S, Jc[2], Jc[5]); }
+    s = 1.0;
+  } else s = b.sinv[k];
   out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
   out.w = mest_weight<EXPW>(b.mest, b.mest_a, out.chi2);
   sw = (useM ? sqrt(out.w) : 1.0) * s;
@@ -249,6 +268,7 @@ struct LidarBatchView {
   const double* dir;
   const double* range;
   const double* sinv;
+  const double* S = nullptr;   // optional general sqrtInvR, n x D x D row major (then sinv is not used)
   const int* qpw_off;  // per term
   const int* tpw_off;
   int mest; double mest_a;
@@ -337,6 +357,7 @@ struct ImuBatchView {
   const double* t;
   const double* meas;
   const double* sinv;
+  const double* S = nullptr;   // optional general sqrtInvR, n x D x D row major (then sinv is not used)
   int mest; double mest_a;
   int is_accel;
   int n_terms, row_base, term_base_global;
@@ -416,6 +437,7 @@ MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bo
 #pragma unroll
   for (int d = 0; d < 3; ++d) ev[d] = pr[d] + bias[d] - m[d];
   double s = b.sinv[k];
+  if (b.S) { sinv_mix3(b.S + 9 * (size_t)k, ev, 1); s = 1.0; }
   out.chi2 = (s * s) * (ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
   out.w = mest_weight(b.mest, b.mest_a, out.chi2);
   double sw = (useM ? sqrt(out.w) : 1.0) * s;
@@ -514,6 +536,10 @@ MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bo
           J[r * ld + rolecol[IMU_ROLE_POSE] + 6 * i + 3 + c] = f * (w0 * Q0[3 * r + c] + w1 * Q1[3 * r + c] + w2 * Q2[3 * r + c]);
         }
     }
+  }
+  if (b.S) {   // general sqrtInvR: J_w = S^T J, column by column over the whole row (columns the term does not write hold zeros or nothing the caller reads)
+    const double* S = b.S + 9 * (size_t)k;
+    for (int c = 0; c < ld; ++c) sinv_mix3(S, J + c, ld);
   }
   return true;
 }
@@ -622,7 +648,8 @@ MC_HD bool imu_sm_term(const ImuSmBatchView& b, const double* x, int k, bool use
   double ev[3];
   const double* m = b.meas + 3 * (size_t)k;
   for (int d = 0; d < 3; ++d) ev[d] = pr[d] + bias[d] - m[d];
-  const double s = b.sinv[k];
+  double s = b.sinv[k];
+  if (b.S) { sinv_mix3(b.S + 9 * (size_t)k, ev, 1); s = 1.0; }
   out.chi2 = (s * s) * (ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
   out.w = mest_weight(b.mest, b.mest_a, out.chi2);
   const double sw = (useM ? sqrt(out.w) : 1.0) * s;
@@ -763,6 +790,10 @@ MC_HD bool imu_sm_term(const ImuSmBatchView& b, const double* x, int k, bool use
         }
     }
   }
+  if (b.S) {   // general sqrtInvR: J_w = S^T J, column by column over the whole row (columns the term does not write hold zeros or nothing the caller reads)
+    const double* S = b.S + 9 * (size_t)k;
+    for (int c = 0; c < ld; ++c) sinv_mix3(S, J + c, ld);
+  }
   return true;
 }
 
@@ -783,6 +814,7 @@ struct StaticReprojBatchView {
   const double* y;
   const double* p;
   const double* sinv;
+  const double* S = nullptr;   // optional general sqrtInvR, n x D x D row major (then sinv is not used)
   int mest; double mest_a;
   int n_obs, n_terms, row_base, term_base_global;
 };
@@ -836,7 +868,9 @@ MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, int k,
   double kp[2], Jc[6];
   project(b.cam.model, b.cam.dist, pp, dk, pc, kp, wantJ ? Jc : nullptr);
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
-  double s = b.sinv[k];
+  const double* Sk = b.S ? b.S + 4 * (size_t)k : nullptr;
+  double s = Sk ? 1.0 : b.sinv[k];
+  if (Sk) sinv_mix2(Sk, e0, e1);
   out.chi2 = (s * s) * (e0 * e0 + e1 * e1);
   out.w = mest_weight(b.mest, b.mest_a, out.chi2);
   double sw = (useM ? sqrt(out.w) : 1.0) * s;
@@ -846,6 +880,11 @@ MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, int k,
   if (rolecol[F2_ROLE_PROJ] >= 0) intrinsics_jacobian(b.cam.model, b.cam.dist, pp, dk, pc, Ji);
   if (rolecol[F2_ROLE_DIST] >= 0) distortion_jacobian(b.cam.model, b.cam.dist, pp, pc, Jd);
   const int pd = b.cam.proj_dim;
+  if (Sk) {   // general sqrtInvR: every row below is linear in the rows of Jc / Ji / Jd
+    for (int c = 0; c < 3; ++c) sinv_mix2(Sk, Jc[c], Jc[3 + c]);
+    if (rolecol[F2_ROLE_PROJ] >= 0) for (int c = 0; c < pd; ++c) sinv_mix2(Sk, Ji[c], Ji[pd + c]);
+    if (rolecol[F2_ROLE_DIST] >= 0) for (int c = 0; c < 4; ++c) sinv_mix2(Sk, Jd[c], Jd[4 + c]);
+  }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     if (!((rmask >> r) & 1)) continue;
@@ -903,6 +942,7 @@ struct GyroPriorBatchView {
   const double* w_pred;   // n x 3: predicted rate in the camera frame (constant)
   const double* meas;     // n x 3
   const double* sinv;
+  const double* S = nullptr;   // optional general sqrtInvR, n x D x D row major (then sinv is not used)
   int mest; double mest_a;
   int n_terms, row_base, term_base_global;
 };
@@ -914,7 +954,8 @@ MC_HD bool gyro_prior_term(const GyroPriorBatchView& b, const double* x, int k, 
   const double* bg = x + b.bias.off;
   const double* m = b.meas + 3 * (size_t)k;
   double ev[3] = {p[0] + bg[0] - m[0], p[1] + bg[1] - m[1], p[2] + bg[2] - m[2]};
-  const double s = b.sinv[k];
+  double s = b.sinv[k];
+  if (b.S) { sinv_mix3(b.S + 9 * (size_t)k, ev, 1); s = 1.0; }
   out.chi2 = (s * s) * (ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
   out.w = mest_weight(b.mest, b.mest_a, out.chi2);
   const double sw = (useM ? sqrt(out.w) : 1.0) * s;
@@ -928,6 +969,10 @@ MC_HD bool gyro_prior_term(const GyroPriorBatchView& b, const double* x, int k, 
       if (rolecol[GP_ROLE_Q] >= 0) J[r * ld + rolecol[GP_ROLE_Q] + c] = sw * b.q.scale * K[3 * r + c];
       if (rolecol[GP_ROLE_BIAS] >= 0) J[r * ld + rolecol[GP_ROLE_BIAS] + c] = (r == c) ? sw * b.bias.scale : 0.0;
     }
+  if (b.S) {   // general sqrtInvR: J_w = S^T J, column by column over the whole row (columns the term does not write hold zeros or nothing the caller reads)
+    const double* S = b.S + 9 * (size_t)k;
+    for (int c = 0; c < ld; ++c) sinv_mix3(S, J + c, ld);
+  }
   return true;
 }
 // ErrorTermTransformation (ABE/src/ErrorTermTransformation.cpp:19-81) over the two expression shapes the front-end

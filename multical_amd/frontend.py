@@ -605,11 +605,23 @@ class OptimizationProblem(object):
 
 # ------------------------------------------------------------------------------------------------ lowering pass
 def _isotropic(invR, what):
+    """The scalar s with sqrtInvR = s I, or -- for a general inverse covariance -- the matrix itself (it then goes to
+    the batch through ProblemSpec.set_inv_r, i.e. mc_set_last_batch_sqrt_inv_r)."""
     invR = np.atleast_2d(np.asarray(invR, dtype=np.float64))
     d = invR[0, 0]
     if not np.allclose(invR, d * np.eye(invR.shape[0]), rtol=1e-12, atol=0.0):
-        raise UnsupportedErrorTerm("%s: the HIP path takes isotropic inverse covariances" % what)
+        if invR.shape[0] != invR.shape[1] or not np.allclose(invR, invR.T, rtol=1e-12, atol=0.0):
+            raise UnsupportedErrorTerm("%s: the inverse covariance is not a symmetric matrix" % what)
+        return invR.copy()
     return float(np.sqrt(d))
+
+
+def _weights(entries, dim):
+    """(scalar array for the batch call, None or the [n, dim, dim] inverse covariances) from a run's per-term entries"""
+    if all(isinstance(e, float) for e in entries):
+        return np.array(entries), None
+    invR = np.stack([e * e * np.eye(dim) if isinstance(e, float) else e for e in entries])
+    return np.ones(len(entries)), invR
 
 
 def _match_t_leaf(T):
@@ -929,36 +941,41 @@ def lower(problem):
         if run is None:
             return
         kind = run_key[0]
+        invR = None
+        if "sinv" in run:
+            run["sinv"], invR = _weights(run["sinv"], 2 if kind == "reproj" else 1 if kind == "lidar" else 3)
         if kind == "reproj":
             first = np.concatenate([[0], np.cumsum(run["counts"])]).astype(np.int32)
-            sp.add_reprojection_batch(run["camera"], run["spline"], run["q_cb"], run["t_cb"], run["toff"], run["obs_time"],
+            op = sp.add_reprojection_batch(run["camera"], run["spline"], run["q_cb"], run["t_cb"], run["toff"], run["obs_time"],
                                       run["obs_q"], run["obs_t"], first, np.array(run["y"]), np.array(run["p"]),
                                       np.array(run["sinv"]), run["pad"], run["mest"].kind, run["mest"].param)
         elif kind == "lidar":
-            sp.add_lidar_batch(run["spline"], run["toff"], run["q_lb"], run["t_lb"], np.array(run["t"]), np.array(run["dir"]),
+            op = sp.add_lidar_batch(run["spline"], run["toff"], run["q_lb"], run["t_lb"], np.array(run["t"]), np.array(run["dir"]),
                                np.array(run["range"]), np.array(run["sinv"]), run["q_pw"], run["t_pw"], run["pad"],
                                run["mest"].kind, run["mest"].param)
         elif kind == "accel":
-            sp.add_accelerometer_batch(run["spline"], run["bias_spline"], run["bias_dv"], run["g"], run["q_ib"], run["r_b"],
+            op = sp.add_accelerometer_batch(run["spline"], run["bias_spline"], run["bias_dv"], run["g"], run["q_ib"], run["r_b"],
                                        np.array(run["t"]), np.array(run["meas"]), np.array(run["sinv"]), run["mest"].kind,
                                        run["mest"].param)
         elif kind == "gyro":
-            sp.add_gyroscope_batch(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], np.array(run["t"]),
+            op = sp.add_gyroscope_batch(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], np.array(run["t"]),
                                    np.array(run["meas"]), np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
         elif kind == "accel_sm":
-            sp.add_accelerometer_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["g"], run["q_ib"], run["r_b"],
+            op = sp.add_accelerometer_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["g"], run["q_ib"], run["r_b"],
                                           run["M"], run["size_effect"], np.array(run["t"]), np.array(run["meas"]),
                                           np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
         elif kind == "gyro_prior":
-            sp.add_gyroscope_prior_batch(run["q"], run["bias"], np.array(run["w_pred"]), np.array(run["meas"]), np.array(run["sinv"]),
+            op = sp.add_gyroscope_prior_batch(run["q"], run["bias"], np.array(run["w_pred"]), np.array(run["meas"]), np.array(run["sinv"]),
                                          run["mest"].kind, run["mest"].param)
         elif kind == "transformation":
             sp.add_transformation_batch(run["qa"], run["ta"], run["qb"], run["tb"], np.array(run["prior_q"]), np.array(run["prior_t"]),
                                         run["wr"], run["wt"], run["mest"].kind, run["mest"].param)
         elif kind == "gyro_sm":
-            sp.add_gyroscope_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], run["q_gi"], run["M"],
+            op = sp.add_gyroscope_batch_sm(run["spline"], run["bias_spline"], run["bias_dv"], run["q_ib"], run["q_gi"], run["M"],
                                       run["Ma"], run["g"], run["r_b"], np.array(run["t"]), np.array(run["meas"]),
                                       np.array(run["sinv"]), run["mest"].kind, run["mest"].param)
+        if invR is not None:
+            sp.set_inv_r(op, invR)
         run_key, run = None, None
 
     def start(key, **fields):

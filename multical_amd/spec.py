@@ -136,6 +136,14 @@ class ProblemSpec(object):
         self.ops.append(("motion", dict(spline=spline, W=_f64(W), order=int(order))))
         return len(self.ops) - 1
 
+    def set_inv_r(self, op, invR):
+        """ErrorTermFs.setInvR with a general matrix per term of batch `op`: invR [n, D, D].  It replaces the batch's
+        isotropic scalars (which stay as placeholders)."""
+        k, d = self.ops[op]
+        invR = _f64(invR)
+        assert invR.ndim == 3 and invR.shape[0] == len(d["sinv"]) and invR.shape[1] == invR.shape[2]
+        d["invR"] = invR.copy()
+
     # ---- bookkeeping ---------------------------------------------------------------------------
     def batch_ops(self):
         return [(i, k, d) for i, (k, d) in enumerate(self.ops) if k not in ("dv", "spline", "camera")]
@@ -217,4 +225,6 @@ class ProblemSpec(object):
                                              d["mest_param"])
             elif k == "motion":
                 api.add_motion_term(sid(d["spline"]), d["W"], d["order"])
+            if "invR" in d:
+                api.set_last_batch_inv_r(d["invR"])
         return ids

@@ -78,6 +78,9 @@ int probe_add_lidar_batch(void* h, int sp, int dtoff, int dq, int dt, int n, con
 int probe_add_motion_term(void* h, int sp, const double* W, int order) {
   Probe* pr = (Probe*)h; PR_TRY describeMotion(pr->P, sp, W, order); return 0; PR_CATCH(pr, -1)
 }
+int probe_set_last_batch_sqrt_inv_r(void* h, int dim, int n, const double* S) {
+  Probe* pr = (Probe*)h; PR_TRY describeSqrtInvR(pr->P, dim, n, S); return 0; PR_CATCH(pr, -1)
+}
 int probe_set_shard(void* h, int rank, int world) { Probe* pr = (Probe*)h; pr->P.rank = rank; pr->P.world = world; return 0; }
 int probe_finalize(void* h) {
   Probe* pr = (Probe*)h;
@@ -155,7 +158,7 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     v.q_cb = P.dvRef(B.dv[0]); v.t_cb = P.dvRef(B.dv[1]); v.toff = P.dvRef(B.dv[2]);
     v.coef_scale = v.qpw_scale = v.tpw_scale = 1.0;
     v.obs_time = B.t.data(); v.obs_first = B.obs_first.data(); v.obs_qpw_off = pr->obs_q_off[bi].data(); v.obs_tpw_off = pr->obs_t_off[bi].data();
-    v.y = B.y.data(); v.p = B.p.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    v.y = B.y.data(); v.p = B.p.data(); v.sinv = B.sinv.data(); v.S = B.S.empty() ? nullptr : B.S.data(); v.mest = B.mest; v.mest_a = B.mest_a;
     int obs = (int)(std::upper_bound(B.obs_first.begin(), B.obs_first.end(), k) - B.obs_first.begin()) - 1;
     F1Common cm;
     f1_common(v, x, obs, cm);
@@ -186,7 +189,7 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     v.bias_dv = P.dvRef(B.dv[0]); v.g = P.dvRef(B.dv[1]); v.q_ib = P.dvRef(B.dv[2]); v.r_b = P.dvRef(B.dv[3]);
     v.g_is_direction = (B.dv[1] >= 0 && P.dvs[B.dv[1]].kind == DV_EUCLIDEAN_DIRECTION) ? 1 : 0;
     v.pose_scale = 1.0; v.bias_scale = B.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
-    v.t = B.t.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    v.t = B.t.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.S = B.S.empty() ? nullptr : B.S.data(); v.mest = B.mest; v.mest_a = B.mest_a;
     v.is_accel = B.kind == KIND_ACCEL;
     int seg = spline_segment(v.pose, B.t[k]);
     rolecol[IMU_ROLE_POSE] = v.pose.first_col >= 0 ? v.pose.first_col + 6 * seg : -1;
@@ -201,7 +204,7 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     v.bias_dv = P.dvRef(B.dv[0]); v.g = P.dvRef(B.dv[1]); v.q_ib = P.dvRef(B.dv[2]); v.r_b = P.dvRef(B.dv[3]);
     v.g_is_direction = P.dvs[B.dv[1]].kind == DV_EUCLIDEAN_DIRECTION ? 1 : 0;
     v.pose_scale = 1.0; v.bias_scale = B.bias_spline >= 0 ? 1.0 : v.bias_dv.scale;
-    v.t = B.t.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    v.t = B.t.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.S = B.S.empty() ? nullptr : B.S.data(); v.mest = B.mest; v.mest_a = B.mest_a;
     v.is_accel = B.kind == KIND_ACCEL_SM;
     v.M = P.dvRef(B.dv[4]); v.M_mask = P.dvs[B.dv[4]].mask;
     v.q_gi = P.dvRef(B.dv[5]); v.Ma = P.dvRef(B.dv[6]); v.Ma_mask = B.dv[6] >= 0 ? P.dvs[B.dv[6]].mask : 0;
@@ -224,7 +227,7 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     v.proj_scale = P.dvs[P.cams[B.cam].dv_proj].scaling;
     v.dist_scale = P.cams[B.cam].dv_dist >= 0 ? P.dvs[P.cams[B.cam].dv_dist].scaling : 1.0;
     v.obs_first = B.obs_first.data(); v.obs_qtc_off = pr->obs_q_off[bi].data(); v.obs_ttc_off = pr->obs_t_off[bi].data();
-    v.term_obs = B.term_obs.data(); v.y = B.y.data(); v.p = B.p.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    v.term_obs = B.term_obs.data(); v.y = B.y.data(); v.p = B.p.data(); v.sinv = B.sinv.data(); v.S = B.S.empty() ? nullptr : B.S.data(); v.mest = B.mest; v.mest_a = B.mest_a;
     int obs = B.term_obs[k];
     rolecol[F2_ROLE_QTC] = col(B.obs_dv_q[obs]); rolecol[F2_ROLE_TTC] = col(B.obs_dv_t[obs]);
     for (int j = 0; j < v.n_chain; ++j) { rolecol[F2_ROLE_CHAIN + 2 * j] = v.chain_q[j].col; rolecol[F2_ROLE_CHAIN + 2 * j + 1] = v.chain_t[j].col; }
@@ -233,7 +236,7 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
   } else if (B.kind == KIND_GYRO_PRIOR) {
     GyroPriorBatchView v;
     v.q = P.dvRef(B.dv[0]); v.bias = P.dvRef(B.dv[1]);
-    v.w_pred = B.p.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.mest = B.mest; v.mest_a = B.mest_a;
+    v.w_pred = B.p.data(); v.meas = B.meas.data(); v.sinv = B.sinv.data(); v.S = B.S.empty() ? nullptr : B.S.data(); v.mest = B.mest; v.mest_a = B.mest_a;
     rolecol[GP_ROLE_Q] = v.q.col; rolecol[GP_ROLE_BIAS] = v.bias.col;
     gyro_prior_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out);
   } else if (B.kind == KIND_TRANSFORMATION) {

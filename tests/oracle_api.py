@@ -165,6 +165,11 @@ class OracleApi(object):
         W = _f64(W)
         self._chk(self.lib.orc_add_motion_term(self.h, C.c_int(spline), _d(W), C.c_int(order)))
 
+    def set_last_batch_inv_r(self, invR):
+        """ErrorTermFs::setInvR on the terms of the batch added last (oracle_unit_capi.hpp)"""
+        invR = _f64(invR)
+        self._chk(self.lib.orc_set_last_terms_inv_r(self.h, C.c_int(invR.shape[0]), C.c_int(invR.shape[1]), _d(invR)))
+
     def finalize(self):
         self._chk(self.lib.orc_finalize(self.h))
         v = [C.c_int() for _ in range(4)]

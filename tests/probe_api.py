@@ -119,6 +119,18 @@ class ProbeApi(object):
         W = _f64(W)
         self._chk(self.L.probe_add_motion_term(self.h, C.c_int(sp), _d(W), C.c_int(order)))
 
+    def set_last_batch_inv_r(self, invR):
+        """sqrtInvR from the product's own mc_compute_matrix_sqrt (the host library needs no GPU for it)"""
+        from multical_amd._lib import load
+        lib = load()
+        invR = _f64(invR)
+        S = np.empty_like(invR)
+        for k in range(invR.shape[0]):
+            A = np.ascontiguousarray(invR[k]); o = np.empty_like(A)
+            assert lib.mc_compute_matrix_sqrt(A.shape[0], A.ctypes.data_as(C.POINTER(C.c_double)), o.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            S[k] = o
+        self._chk(self.L.probe_set_last_batch_sqrt_inv_r(self.h, C.c_int(S.shape[1]), C.c_int(S.shape[0]), _d(S)))
+
     def set_shard(self, rank, world):
         self.L.probe_set_shard(self.h, C.c_int(rank), C.c_int(world))
 

@@ -39,7 +39,7 @@ def test_every_term_matches_oracle(probe, small_oracle, use_mest):
             continue
         Ja, ea = o.term_weighted_jacobian(t, use_mest)
         Jp, ep, c = probe.term(t, use_mest)
-        worst_j = max(worst_j, np.abs(Ja - Jp).max() / np.abs(Ja).max())
+        worst_j = max(worst_j, np.abs(Ja - Jp).max() / max(np.abs(Ja).max(), 1e-300))
         worst_e = max(worst_e, np.abs(ea - ep).max() / max(1e-9, np.abs(ea).max()))
         worst_c = max(worst_c, abs(c - chi[t]) / max(1e-9, chi[t]))
     assert worst_j < 1e-9 and worst_e < 1e-9 and worst_c < 1e-9, (worst_j, worst_e, worst_c)
