@@ -44,7 +44,8 @@ enum {
   MC_DV_SPLINE_COEFF = 4,        /* DesignVariableMappedVector<D> (created by mc_add_spline) */
   MC_DV_PROJECTION = 5,          /* DesignVariableAdapter<Projection>: 4/5/6 params         */
   MC_DV_DISTORTION = 6,          /* DesignVariableAdapter<Distortion>: 4 params             */
-  MC_DV_MATRIX_BASIC = 7         /* MatrixBasic (created by mc_add_matrix_design_variable)  */
+  MC_DV_MATRIX_BASIC = 7,        /* MatrixBasic (created by mc_add_matrix_design_variable)  */
+  MC_DV_HOMOGENEOUS_POINT = 8    /* HomogeneousPoint      : 4 params, kept at unit norm, minimal 3 (aslam_backend_expressions/src/HomogeneousPoint.cpp) */
 };
 enum { MC_PROJ_PINHOLE = 0, MC_PROJ_OMNI = 1, MC_PROJ_DS = 2 };
 enum { MC_DIST_NONE = 0, MC_DIST_RADTAN = 1, MC_DIST_EQUI = 2 };
@@ -142,6 +143,11 @@ int mc_add_lidar_batch(mc_context* ctx, int pose_spline, int dv_time_offset, int
                        const double* t, const double* dir /* [n,3] unit */, const double* range,
                        const double* sqrt_inv_r, const int* dv_q_p_w, const int* dv_t_p_w, double time_padding,
                        int mest_kind, double mest_param);
+/* Landmarks that are design variables (kalibr_camera_calibration with estimateLandmarks: the target corners become
+ * HomogeneousPointDv and ReprojectionError's point is T * landmark; aslam_backend_expressions/src/HomogeneousPoint.cpp:44-52,
+ * HomogeneousExpressionNode.cpp:77-82).  For the static reprojection batch added last: per term the dv id of its
+ * MC_DV_HOMOGENEOUS_POINT, or -1 to keep the constant p_target.  The state of a landmark must keep w >= 0. */
+int mc_set_last_batch_landmarks(mc_context* ctx, int n, const int* dv_landmark);
 /* ErrorTermFs<D>::setSqrtInvR for the terms of the batch added last (aslam_backend/include/aslam/backend/ErrorTerm.hpp:246,
  * implementation/ErrorTerm.hpp:96-192): S is [n, dim, dim] row major, one general sqrtInvR per term (invR = S S^T; the weighted
  * error is sqrt(w) S^T e, the weighted Jacobian sqrt(w) S^T J, chi2 = e^T invR e); it replaces the scalars given with the batch.

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mc_add_lidar_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _ip, _ip,
                                      C.c_double, C.c_int, C.c_double]),
     "mc_add_motion_term": (C.c_int, [_ctx, C.c_int, _dp, C.c_int]),
+    "mc_set_last_batch_landmarks": (C.c_int, [_ctx, C.c_int, _ip]),
     "mc_set_last_batch_sqrt_inv_r": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
     "mc_compute_matrix_sqrt": (C.c_int, [C.c_int, _dp, _dp]),
     "mc_set_shard": (C.c_int, [_ctx, C.c_int, C.c_int]),

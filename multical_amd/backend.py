@@ -155,6 +155,11 @@ class HipApi(object):
         W = _f64(W)
         self._chk(self.lib.mc_add_motion_term(self.ctx, spline, _dp(W), order))
 
+    def set_last_batch_landmarks(self, dv_landmark):
+        """per term of the static reprojection batch added last: the HomogeneousPoint dv id, or -1"""
+        dv = _i32(dv_landmark)
+        self._chk(self.lib.mc_set_last_batch_landmarks(self.ctx, dv.size, _ip(dv)))
+
     def compute_matrix_sqrt(self, A):
         """sm::eigen::computeMatrixSqrt: S with A = S S^T (what ErrorTermFs.setInvR applies to invR)"""
         A = _f64(A)

@@ -26,7 +26,7 @@
 namespace mc {
 
 enum { DV_EUCLIDEAN_POINT = 0, DV_ROTATION_QUATERNION = 1, DV_SCALAR = 2, DV_EUCLIDEAN_DIRECTION = 3,
-       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6, DV_MATRIX_BASIC = 7 };
+       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6, DV_MATRIX_BASIC = 7, DV_HOMOGENEOUS_POINT = 8 };
 enum { KIND_REPROJ = 0, KIND_STATIC_REPROJ = 1, KIND_ACCEL = 2, KIND_GYRO = 3, KIND_LIDAR = 4, KIND_MOTION = 5,
        KIND_ACCEL_SM = 6, KIND_GYRO_SM = 7, KIND_GYRO_PRIOR = 8, KIND_TRANSFORMATION = 9, N_KINDS = 10 };
 // terms over a handful of global design variables (the initialisation problems): every term of a batch writes the same blocks
@@ -84,6 +84,7 @@ struct Batch {
   std::vector<double> t, y, p, sinv, meas, range;
   std::vector<double> S;   // optional general sqrtInvR, n_terms x dim x dim row major (mc_set_last_batch_sqrt_inv_r)
   std::vector<int> obs_first, obs_dv_q, obs_dv_t, term_dv_q, term_dv_t, term_obs;
+  std::vector<int> term_dv_lm;   // static reprojection: per term the HomogeneousPoint landmark, or -1 (constant target point)
   std::vector<int> chain_q, chain_t;
   // motion term
   std::vector<double> Qband;  // n_coeff x S blocks of dim x dim, Qband[(i*S + d)*D*D ...] = Q(i, i-d)
@@ -192,6 +193,7 @@ struct Problem {
       case DV_EUCLIDEAN_DIRECTION: if (n != 3) throw std::invalid_argument("EuclideanDirection needs a 3-vector"); d.dim = 2; d.nparam = 10; break;
       case DV_PROJECTION: if (n < 4 || n > 6) throw std::invalid_argument("projection needs 4..6 parameters"); d.dim = n; d.nparam = n; break;
       case DV_DISTORTION: if (n != 4) throw std::invalid_argument("distortion needs 4 parameters"); d.dim = 4; d.nparam = 4; break;
+      case DV_HOMOGENEOUS_POINT: if (n != 4) throw std::invalid_argument("HomogeneousPoint needs 4 parameters"); d.dim = 3; d.nparam = 4; break;
       default: throw std::invalid_argument("unknown design variable kind");
     }
     if (kind == DV_EUCLIDEAN_DIRECTION) {
@@ -203,6 +205,11 @@ struct Problem {
       ypr0_to_r(std::asin(-u0), std::atan2(u1, u2), R);
       for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) x.push_back(R[3 * j + i]);
       x.push_back(m);
+    } else if (kind == DV_HOMOGENEOUS_POINT) {
+      // HomogeneousPoint constructor (ABE/src/HomogeneousPoint.cpp:7-13): the point is kept with unit 4-norm
+      const double nrm = std::sqrt(params[0] * params[0] + params[1] * params[1] + params[2] * params[2] + params[3] * params[3]);
+      if (!(nrm > 0.0)) throw std::invalid_argument("HomogeneousPoint: the zero vector is not a point");
+      for (int i = 0; i < 4; ++i) x.push_back(params[i] * (1.0 / nrm));
     } else {
       x.insert(x.end(), params, params + n);
     }
@@ -620,7 +627,28 @@ inline void Problem::finalize() {
         if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
           throw std::invalid_argument("a design variable plays two roles in one error term");
         int fp = internFootprint(pattern, written);
-        pushGroup(b.obs_first[o], b.obs_first[o + 1] - b.obs_first[o], fp, o, (double)o, 1 << 30);
+        if (b.term_dv_lm.empty()) {
+          pushGroup(b.obs_first[o], b.obs_first[o + 1] - b.obs_first[o], fp, o, (double)o, 1 << 30);
+          continue;
+        }
+        // landmarks that are design variables: a term whose landmark is active has a Jacobian block of its own, so it
+        // forms a group of its own (footprint = the observation's blocks + the landmark); runs of terms over constant
+        // or inactive points stay together
+        int run0 = b.obs_first[o];
+        for (int k = b.obs_first[o]; k < b.obs_first[o + 1]; ++k) {
+          const int lb = b.term_dv_lm[k] >= 0 ? blk(b.term_dv_lm[k]) : -1;
+          if (lb < 0) continue;
+          if (k > run0) pushGroup(run0, k - run0, fp, o, (double)o, 1 << 30);
+          std::vector<int> pat2 = pattern;
+          std::vector<std::array<int, 3>> wr2 = written;
+          pat2.push_back(lb); wr2.push_back({F2_ROLE_LM, lb, 1});
+          std::sort(pat2.begin(), pat2.end());
+          if (std::adjacent_find(pat2.begin(), pat2.end()) != pat2.end())
+            throw std::invalid_argument("a design variable plays two roles in one error term");
+          pushGroup(k, 1, internFootprint(pat2, wr2), o, (double)o, 1 << 30);
+          run0 = k + 1;
+        }
+        if (b.obs_first[o + 1] > run0) pushGroup(run0, b.obs_first[o + 1] - run0, fp, o, (double)o, 1 << 30);
       }
     }
   }

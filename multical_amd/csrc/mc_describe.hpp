@@ -195,6 +195,18 @@ inline void describeSqrtInvR(Problem& P, int dim, int n, const double* S) {
   if (dim == 1) b.sinv.assign(S, S + n);
   else b.S.assign(S, S + (size_t)n * dim * dim);
 }
+// ReprojectionError over landmarks that are HomogeneousPoint design variables (kalibr_camera_calibration with
+// estimateLandmarks: the target corners become HomogeneousPointDv, CameraCalibrator.py:195-219): for the static
+// reprojection batch added last, per term the landmark's dv id, or -1 to keep the constant p_target.
+inline void describeLandmarks(Problem& P, int n, const int* dv_lm) {
+  requireOpen(P);
+  if (P.batches.empty() || P.batches.back().kind != KIND_STATIC_REPROJ)
+    throw std::invalid_argument("landmark design variables follow a static reprojection batch");
+  Batch& b = P.batches.back();
+  if (n != b.n_terms || !dv_lm) throw std::invalid_argument("one landmark id (or -1) per term of the batch");
+  for (int k = 0; k < n; ++k) if (dv_lm[k] >= 0) P.checkDv(dv_lm[k], DV_HOMOGENEOUS_POINT);
+  b.term_dv_lm.assign(dv_lm, dv_lm + n);
+}
 inline void describeMotion(Problem& P, int spline, const double* W, int order) {
   requireOpen(P);
   if (spline < 0 || spline >= (int)P.splines.size()) throw std::invalid_argument("spline id out of range");

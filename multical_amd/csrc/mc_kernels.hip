@@ -866,7 +866,7 @@ __global__ __launch_bounds__(64) void k_static_common(const StaticReprojBatchVie
   f2_common(views[gr.batch], x, gr.aux, cm);
   out[g] = cm;
 }
-enum { F2_MAXCORE = 6 + 6 * F2_MAX_CHAIN + 6 + 4 + 1, F2_NE = (F2_MAXCORE * (F2_MAXCORE + 1) / 2 + 255) / 256 };
+enum { F2_MAXCORE = 6 + 3 + 6 * F2_MAX_CHAIN + 6 + 4 + 1, F2_NE = (F2_MAXCORE * (F2_MAXCORE + 1) / 2 + 255) / 256 };
 template <bool BUILD>
 __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticReprojBatchView* __restrict__ views, DevCommon dc,
                                                 const GroupRec* __restrict__ groups, const ImageRec* __restrict__ runs,
@@ -882,7 +882,9 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
   const ImageRec run = runs[blockIdx.x];
   const StaticReprojBatchView b = views[groups[run.first].batch];
   const int nch = b.n_chain, pd = b.cam.proj_dim, nd = b.cam.dist_off >= 0 ? 4 : 0;
-  const int ncore = 6 + 6 * nch + pd + nd + 1, ecol = ncore - 1;
+  // batches with landmark design variables carry 3 more per-observation columns (a group is then a single term)
+  const int L = b.lm_off ? 3 : 0, npo = 6 + L;
+  const int ncore = npo + 6 * nch + pd + nd + 1, ecol = ncore - 1;
   const int nt = (ncore + 15) >> 4, ntile = nt * (nt + 1) / 2;
   const int E = ncore * (ncore + 1) / 2;
   int ea[F2_NE], eb[F2_NE];
@@ -892,9 +894,10 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
       int role, d;
       if (tid < 3) { role = F2_ROLE_QTC; d = tid; }
       else if (tid < 6) { role = F2_ROLE_TTC; d = tid - 3; }
-      else if (tid < 6 + 6 * nch) { const int j = (tid - 6) / 6, k = (tid - 6) - 6 * j; role = F2_ROLE_CHAIN + 2 * j + (k >= 3 ? 1 : 0); d = k >= 3 ? k - 3 : k; }
-      else if (tid < 6 + 6 * nch + pd) { role = F2_ROLE_PROJ; d = tid - (6 + 6 * nch); }
-      else { role = F2_ROLE_DIST; d = tid - (6 + 6 * nch + pd); }
+      else if (tid < npo) { role = F2_ROLE_LM; d = tid - 6; }
+      else if (tid < npo + 6 * nch) { const int j = (tid - npo) / 6, k = (tid - npo) - 6 * j; role = F2_ROLE_CHAIN + 2 * j + (k >= 3 ? 1 : 0); d = k >= 3 ? k - 3 : k; }
+      else if (tid < npo + 6 * nch + pd) { role = F2_ROLE_PROJ; d = tid - (npo + 6 * nch); }
+      else { role = F2_ROLE_DIST; d = tid - (npo + 6 * nch + pd); }
       crole[tid] = role; cdim[tid] = d;
     }
 #pragma unroll
@@ -925,13 +928,14 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
       for (int i = tid; i < ntile * 256; i += 256) gram[i] = 0.0;
       if (f.rolecol[F2_ROLE_QTC] >= 0) rc[F2_ROLE_QTC] = 0;
       if (f.rolecol[F2_ROLE_TTC] >= 0) rc[F2_ROLE_TTC] = 3;
+      if (L && f.rolecol[F2_ROLE_LM] >= 0) rc[F2_ROLE_LM] = 6;
 #pragma unroll
       for (int j = 0; j < F2_MAX_CHAIN; ++j) {
-        if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j] >= 0) rc[F2_ROLE_CHAIN + 2 * j] = 6 + 6 * j;
-        if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j + 1] >= 0) rc[F2_ROLE_CHAIN + 2 * j + 1] = 9 + 6 * j;
+        if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j] >= 0) rc[F2_ROLE_CHAIN + 2 * j] = npo + 6 * j;
+        if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j + 1] >= 0) rc[F2_ROLE_CHAIN + 2 * j + 1] = npo + 3 + 6 * j;
       }
-      if (f.rolecol[F2_ROLE_PROJ] >= 0) rc[F2_ROLE_PROJ] = 6 + 6 * nch;
-      if (nd && f.rolecol[F2_ROLE_DIST] >= 0) rc[F2_ROLE_DIST] = 6 + 6 * nch + pd;
+      if (f.rolecol[F2_ROLE_PROJ] >= 0) rc[F2_ROLE_PROJ] = npo + 6 * nch;
+      if (nd && f.rolecol[F2_ROLE_DIST] >= 0) rc[F2_ROLE_DIST] = npo + 6 * nch + pd;
     }
     __syncthreads();
     f64x4 acc[6];
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
         TermOut out;
         double* row = rows + tid * ld;
         // the inactive roles' columns keep whatever the tile held: their Gram entries are never flushed
-        f2_term_cm(b, cm, term, dc.useM != 0, BUILD, rc, BUILD ? row - r * ld : nullptr, ld, e, out, BUILD ? (1 << r) : 3);
+        f2_term_cm(b, cm, dc.x, term, dc.useM != 0, BUILD, rc, BUILD ? row - r * ld : nullptr, ld, e, out, BUILD ? (1 << r) : 3);
         if (r == 0) { Jacc += out.w * out.chi2; dc.chi2[b.term_base_global + term] = out.chi2; }
         if (dc.e) {
           if (BUILD) dc.e[b.row_base + 2 * term + r] = -e[r];
@@ -995,7 +999,7 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
         const int a = ea[j], bq = eb[j];
         const int ta = a >> 4, tb = bq >> 4, i = a & 15, jj = bq & 15;
         const double m = gram[((tb * (tb + 1) / 2 + ta) * 4 + (i >> 2)) * 64 + (i & 3) * 16 + jj];
-        if (a >= 6) { shared_acc[j] += m; continue; }
+        if (a >= npo) { shared_acc[j] += m; continue; }
         const int la = lcol[a];
         if (la < 0) continue;
         if (bq == ecol) { atomic_add_f64(dc.rhs + global_col(f, la), -m); continue; }
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
 #pragma unroll
   for (int j = 0; j < F2_NE; ++j) {
     const int idx = tid + 256 * j;
-    if (idx >= E || ea[j] == ecol || ea[j] < 6) continue;
+    if (idx >= E || ea[j] == ecol || ea[j] < npo) continue;
     const int la = lcol[ea[j]];
     if (la < 0) continue;
     const double m = shared_acc[j];
@@ -1371,7 +1375,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdRec* __restrict__ recs,
   UpdRec u = recs[i];
   const double* d = dx + u.col;
   double* p = x + u.off;
-  if (u.kind == DV_ROTATION_QUATERNION) {
+  if (u.kind == DV_ROTATION_QUATERNION || u.kind == DV_HOMOGENEOUS_POINT) {   // both: sm::kinematics::updateQuat (HomogeneousPoint.cpp:26-32)
     double dq[3] = {d[0] * u.scaling, d[1] * u.scaling, d[2] * u.scaling};
     double q[4] = {p[0], p[1], p[2], p[3]}, o[4];
     update_quat(q, dq, o);
@@ -1667,7 +1671,7 @@ void mc_context::uploadStructure() {
       if (b.kind == KIND_STATIC_REPROJ) {
         if ((int)b.chain_q.size() > F2_MAX_CHAIN) throw std::runtime_error("camera chain longer than F2_MAX_CHAIN");
         const CameraRec& c = P.cams[b.cam];
-        const int ncore = 6 + 6 * (int)b.chain_q.size() + P.dvs[c.dv_proj].dim + (c.dv_dist >= 0 ? 4 : 0) + 1;
+        const int ncore = 6 + (b.term_dv_lm.empty() ? 0 : 3) + 6 * (int)b.chain_q.size() + P.dvs[c.dv_proj].dim + (c.dv_dist >= 0 ? 4 : 0) + 1;
         L.static_ld = std::max(L.static_ld, ncore | 1);   // odd stride: conflict-free row writes and column reads
         L.lds_bytes = 256 * L.static_ld * (int)sizeof(double);
       }
@@ -1762,6 +1766,13 @@ void mc_context::uploadStructure() {
       v.dist_scale = P.cams[b.cam].dv_dist >= 0 ? P.dvs[P.cams[b.cam].dv_dist].scaling : 1.0;
       v.obs_first = d->obs_first.p; v.obs_qtc_off = d->obs_q_off.p; v.obs_ttc_off = d->obs_t_off.p; v.term_obs = d->term_obs.p;
       v.y = d->y.p; v.p = d->p.p; v.sinv = d->sinv.p; v.S = b.S.empty() ? nullptr : d->S.p;
+      if (!b.term_dv_lm.empty()) {   // landmark design variables: per term the parameter offset of the point, or -1
+        std::vector<int> lo(b.term_dv_lm.size(), -1);
+        for (size_t k = 0; k < lo.size(); ++k)
+          if (b.term_dv_lm[k] >= 0) { lo[k] = P.dvs[b.term_dv_lm[k]].off; v.lm_scale = P.dvs[b.term_dv_lm[k]].scaling; }
+        d->term_q_off.upload(lo);
+        v.lm_off = d->term_q_off.p;
+      }
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
       v.row_base = b.row_base; v.term_base_global = term_base;
       sviews.push_back(v);
@@ -2139,6 +2150,11 @@ int mc_add_motion_term(mc_context* ctx, int spline, const double* W, int error_t
 }
 int mc_set_last_batch_sqrt_inv_r(mc_context* ctx, int dim, int n, const double* S) {
   MC_TRY describeSqrtInvR(ctx->P, dim, n, S);
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_set_last_batch_landmarks(mc_context* ctx, int n, const int* dv_landmark) {
+  MC_TRY describeLandmarks(ctx->P, n, dv_landmark);
   return 0;
   MC_CATCH(ctx, -1)
 }

@@ -18,7 +18,7 @@
 
 namespace mc {
 
-enum { MC_MAX_ROLES = 12 };
+enum { MC_MAX_ROLES = 13 };
 constexpr int S6 = 6;  // spline order handled by the kernels (Multical: splineOrder = 6 everywhere)
 
 struct DvRef {
@@ -800,8 +800,9 @@ MC_HD bool imu_sm_term(const ImuSmBatchView& b, const double* x, int k, bool use
 // ------------------------------------------------------------------------------------------------
 // F2: ReprojectionError with camera design variables over a static chain
 //   p_c = B_{n-1} * ... * B_0 * inverse(T_t_c) * p      (CameraCalibrator.py:195-212)
-// roles: 0 q_t_c, 1 t_t_c, 2+2j / 3+2j = q / t of baseline j (j < 4), 10 projection, 11 distortion
-enum { F2_ROLE_QTC = 0, F2_ROLE_TTC = 1, F2_ROLE_CHAIN = 2, F2_ROLE_PROJ = 10, F2_ROLE_DIST = 11, F2_MAX_CHAIN = 4 };
+// roles: 0 q_t_c, 1 t_t_c, 2+2j / 3+2j = q / t of baseline j (j < 4), 10 projection, 11 distortion, 12 landmark
+// (a HomogeneousPoint design variable in place of the constant target point)
+enum { F2_ROLE_QTC = 0, F2_ROLE_TTC = 1, F2_ROLE_CHAIN = 2, F2_ROLE_PROJ = 10, F2_ROLE_DIST = 11, F2_ROLE_LM = 12, F2_MAX_CHAIN = 4 };
 struct StaticReprojBatchView {
   CameraView cam;
   int n_chain;
@@ -815,6 +816,8 @@ struct StaticReprojBatchView {
   const double* p;
   const double* sinv;
   const double* S = nullptr;   // optional general sqrtInvR, n x D x D row major (then sinv is not used)
+  const int* lm_off = nullptr;   // optional, per term: parameter offset of the landmark (HomogeneousPoint), or -1
+  double lm_scale = 1.0;
   int mest; double mest_a;
   int n_obs, n_terms, row_base, term_base_global;
 };
@@ -854,19 +857,41 @@ MC_HD void f2_common(const StaticReprojBatchView& b, const double* x, int obs, F
   for (int i = 0; i < 4; ++i) cm.dk[i] = b.cam.dist_off >= 0 ? x[b.cam.dist_off + i] : 0.0;
 }
 // rmask: bit r set = write Jacobian row r (to J + r * ld); the row-per-thread kernel asks for one row only
-MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, int k, bool useM, bool wantJ, const int* rolecol,
-                      double* J, int ld, double* e, TermOut& out, int rmask = 3) {
+MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, const double* x, int k, bool useM, bool wantJ,
+                      const int* rolecol, double* J, int ld, double* e, TermOut& out, int rmask = 3) {
   const Rigid& T = cm.T;
   const Rigid& Tinv = cm.Tinv;
   const Rigid* Bj = cm.Bj;
   const double* pp = cm.pp;
   const double* dk = cm.dk;
-  const double* pt = b.p + 3 * (size_t)k;
+  // the target point: a constant (x, y, z, 1) or the state of a HomogeneousPoint design variable (unit 4-vector)
+  const int lo = b.lm_off ? b.lm_off[k] : -1;
+  double ph[4];
+  if (lo >= 0) { ph[0] = x[lo]; ph[1] = x[lo + 1]; ph[2] = x[lo + 2]; ph[3] = x[lo + 3]; }
+  else { const double* pt = b.p + 3 * (size_t)k; ph[0] = pt[0]; ph[1] = pt[1]; ph[2] = pt[2]; ph[3] = 1.0; }
   double pc[3];
-  m3_mulv(T.C, pt, pc);
-  pc[0] += T.r[0]; pc[1] += T.r[1]; pc[2] += T.r[2];
+  m3_mulv(T.C, ph, pc);
+  pc[0] += ph[3] * T.r[0]; pc[1] += ph[3] * T.r[1]; pc[2] += ph[3] * T.r[2];
   double kp[2], Jc[6];
-  project(b.cam.model, b.cam.dist, pp, dk, pc, kp, wantJ ? Jc : nullptr);
+  // homogeneousToKeypoint: a point with w < 0 is projected through -p.  The pinhole Jacobian overload returns before
+  // that branch and differentiates at +p (aslam_cameras/.../implementation/PinholeProjection.hpp:149-198); the omni and
+  // double-sphere overloads negate p and J (OmniProjection.hpp:219-228, DoubleSphereProjection.hpp:259-268).  The
+  // intrinsics / distortion Jacobians take the sign branch in every model (:391-416).
+  const bool negw = ph[3] < 0.0;
+  double ps[3] = {pc[0], pc[1], pc[2]};
+  if (!negw) {
+    project(b.cam.model, b.cam.dist, pp, dk, pc, kp, wantJ ? Jc : nullptr);
+  } else {
+    ps[0] = -pc[0]; ps[1] = -pc[1]; ps[2] = -pc[2];
+    if (b.cam.model == 0) {   // pinhole
+      project(b.cam.model, b.cam.dist, pp, dk, ps, kp, nullptr);
+      double unused[2];
+      if (wantJ) project(b.cam.model, b.cam.dist, pp, dk, pc, unused, Jc);
+    } else {
+      project(b.cam.model, b.cam.dist, pp, dk, ps, kp, wantJ ? Jc : nullptr);
+      if (wantJ) for (int c = 0; c < 6; ++c) Jc[c] = -Jc[c];
+    }
+  }
   double e0 = b.y[2 * (size_t)k] - kp[0], e1 = b.y[2 * (size_t)k + 1] - kp[1];
   const double* Sk = b.S ? b.S + 4 * (size_t)k : nullptr;
   double s = Sk ? 1.0 : b.sinv[k];
@@ -877,8 +902,8 @@ MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, int k,
   e[0] = sw * e0; e[1] = sw * e1;
   if (!wantJ) return true;
   double Ji[12], Jd[8];
-  if (rolecol[F2_ROLE_PROJ] >= 0) intrinsics_jacobian(b.cam.model, b.cam.dist, pp, dk, pc, Ji);
-  if (rolecol[F2_ROLE_DIST] >= 0) distortion_jacobian(b.cam.model, b.cam.dist, pp, pc, Jd);
+  if (rolecol[F2_ROLE_PROJ] >= 0) intrinsics_jacobian(b.cam.model, b.cam.dist, pp, dk, ps, Ji);
+  if (rolecol[F2_ROLE_DIST] >= 0) distortion_jacobian(b.cam.model, b.cam.dist, pp, ps, Jd);
   const int pd = b.cam.proj_dim;
   if (Sk) {   // general sqrtInvR: every row below is linear in the rows of Jc / Ji / Jd
     for (int c = 0; c < 3; ++c) sinv_mix2(Sk, Jc[c], Jc[3 + c]);
@@ -890,8 +915,19 @@ MC_HD bool f2_term_cm(const StaticReprojBatchView& b, const F2Common& cm, int k,
     if (!((rmask >> r) & 1)) continue;
     double* row = J + r * ld;
     double a[3] = {-sw * Jc[3 * r], -sw * Jc[3 * r + 1], -sw * Jc[3 * r + 2]};
-    double u[3] = {a[0], a[1], a[2]}, v[3];
+    // through HomogeneousExpressionNodeMultiply (ABE/src/HomogeneousExpressionNode.cpp:77-82):
+    //   lhs: chain * boxMinus(p_c) = [w a, a x p_c]    rhs (the landmark): chain * T, then quatInvS(p) (HomogeneousPoint.cpp:44-52)
+    double u[3] = {ph[3] * a[0], ph[3] * a[1], ph[3] * a[2]}, v[3];
     v3_cross(a, pc, v);
+    if (rolecol[F2_ROLE_LM] >= 0) {
+      double g[4];
+      m3_tmulv(T.C, a, g);
+      g[3] = a[0] * T.r[0] + a[1] * T.r[1] + a[2] * T.r[2];
+      const double h = 0.5 * b.lm_scale;
+      row[rolecol[F2_ROLE_LM]] = h * (g[0] * ph[3] + g[1] * ph[2] - g[2] * ph[1] - g[3] * ph[0]);
+      row[rolecol[F2_ROLE_LM] + 1] = h * (-g[0] * ph[2] + g[1] * ph[3] + g[2] * ph[0] - g[3] * ph[1]);
+      row[rolecol[F2_ROLE_LM] + 2] = h * (g[0] * ph[1] - g[1] * ph[0] + g[2] * ph[3] - g[3] * ph[2]);
+    }
     // top-down through Multiply(B_j, rest): lhs gets the chain, rhs gets chain * boxTimes(B_j)
 #pragma unroll
     for (int jj = 0; jj < F2_MAX_CHAIN; ++jj) {
@@ -1051,7 +1087,7 @@ MC_HD bool f2_term(const StaticReprojBatchView& b, const double* x, int k, bool 
                    double* J, int ld, double* e, TermOut& out, int rmask = 3) {
   F2Common cm;
   f2_common(b, x, b.term_obs[k], cm);
-  return f2_term_cm(b, cm, k, useM, wantJ, rolecol, J, ld, e, out, rmask);
+  return f2_term_cm(b, cm, x, k, useM, wantJ, rolecol, J, ld, e, out, rmask);
 }
 
 }  // namespace mc

@@ -10,7 +10,7 @@ object that offers the C-ABI call surface (the HIP backend here; the CPU oracle 
 import numpy as np
 
 DV_EUCLIDEAN_POINT, DV_ROTATION_QUATERNION, DV_SCALAR, DV_EUCLIDEAN_DIRECTION = 0, 1, 2, 3
-DV_SPLINE_COEFF, DV_PROJECTION, DV_DISTORTION, DV_MATRIX_BASIC = 4, 5, 6, 7
+DV_SPLINE_COEFF, DV_PROJECTION, DV_DISTORTION, DV_MATRIX_BASIC, DV_HOMOGENEOUS_POINT = 4, 5, 6, 7, 8
 PROJ_PINHOLE, PROJ_OMNI, PROJ_DS = 0, 1, 2
 DIST_NONE, DIST_RADTAN, DIST_EQUI = 0, 1, 2
 MEST_NONE, MEST_HUBER, MEST_CAUCHY, MEST_GEMAN_MCCLURE, MEST_BZ, MEST_BLAKE_ZISSERMAN = range(6)
@@ -136,6 +136,13 @@ class ProblemSpec(object):
         self.ops.append(("motion", dict(spline=spline, W=_f64(W), order=int(order))))
         return len(self.ops) - 1
 
+    def set_landmarks(self, op, handles):
+        """landmarks as design variables for static reprojection batch `op`: per term the handle of a
+        DV_HOMOGENEOUS_POINT, or None / -1 to keep the constant target point"""
+        k, d = self.ops[op]
+        assert k == "static_reproj" and len(handles) == len(d["sinv"])
+        d["landmarks"] = [(-1 if h is None else h) for h in handles]
+
     def set_inv_r(self, op, invR):
         """ErrorTermFs.setInvR with a general matrix per term of batch `op`: invR [n, D, D].  It replaces the batch's
         isotropic scalars (which stay as placeholders)."""
@@ -225,6 +232,8 @@ class ProblemSpec(object):
                                              d["mest_param"])
             elif k == "motion":
                 api.add_motion_term(sid(d["spline"]), d["W"], d["order"])
+            if "landmarks" in d:
+                api.set_last_batch_landmarks(_i32([dvid(h) for h in d["landmarks"]]))
             if "invR" in d:
                 api.set_last_batch_inv_r(d["invR"])
         return ids

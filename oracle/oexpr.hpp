@@ -63,6 +63,24 @@ struct RotationQuaternion : DesignVariable {
   void revertUpdate() override { q = pq; C = quat2r(q); }
   void getParameters(std::vector<double>& o) const override { o = q.v; }
 };
+// ABE/src/HomogeneousPoint.cpp:7-81
+struct HomogeneousPointDv : DesignVariable {
+  Mat p, pp;
+  explicit HomogeneousPointDv(const double* v) : p(4, 1), pp(4, 1) {
+    double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    double recip = 1.0 / n;
+    for (int i = 0; i < 4; ++i) p[i] = pp[i] = v[i] * recip;
+  }
+  int minimalDimensions() const override { return 3; }
+  void update(const double* dp) override {
+    pp = p;
+    Mat d(3, 1);
+    for (int i = 0; i < 3; ++i) d[i] = dp[i];
+    p = updateQuat(p, d);
+  }
+  void revertUpdate() override { p = pp; }
+  void getParameters(std::vector<double>& o) const override { o = p.v; }
+};
 // ABE/src/EuclideanDirection.cpp:5-77
 struct EuclideanDirection : DesignVariable {
   Mat C, pC;
@@ -211,6 +229,13 @@ struct RotationQuaternionNode : RotationNode {  // ABE/src/RotationQuaternion.cp
   explicit RotationQuaternionNode(RotationQuaternion* d) : dv(d) {}
   Mat toRotationMatrix() override { return dv->C; }
   void evalJ(JacobianContainer& jc, const Mat* chain) override { jc.add(dv, chain ? *chain : Mat::Identity(3)); }
+  void getDvs(std::set<DesignVariable*>& s) override { s.insert(dv); }
+};
+struct HomogeneousPointNode : HomogeneousNode {  // ABE/src/HomogeneousPoint.cpp:39-57
+  HomogeneousPointDv* dv;
+  explicit HomogeneousPointNode(HomogeneousPointDv* d) : dv(d) {}
+  Mat toHomogeneous() override { return dv->p; }
+  void evalJ(JacobianContainer& jc, const Mat* chain) override { jc.add(dv, chainOr(chain, quatInvS(dv->p))); }
   void getDvs(std::set<DesignVariable*>& s) override { s.insert(dv); }
 };
 struct EuclideanPointNode : EuclideanNode {  // ABE/src/EuclideanPoint.cpp

@@ -88,6 +88,16 @@ inline Mat axisAngle2quat(const Mat& a) {
   return q;
 }
 
+// SM/sm_kinematics/src/quaternion_algebra.cpp:355-372  quatInvS (4x3)
+inline Mat quatInvS(const Mat& qq) {
+  double q0 = 0.5 * qq[0], q1 = 0.5 * qq[1], q2 = 0.5 * qq[2], q3 = 0.5 * qq[3];
+  Mat S(4, 3);
+  S(0, 0) = q3;  S(0, 1) = -q2; S(0, 2) = q1;
+  S(1, 0) = q2;  S(1, 1) = q3;  S(1, 2) = -q0;
+  S(2, 0) = -q1; S(2, 1) = q0;  S(2, 2) = q3;
+  S(3, 0) = -q0; S(3, 1) = -q1; S(3, 2) = -q2;
+  return S;
+}
 // SM/sm_kinematics/src/quaternion_algebra.cpp:302-318  updateQuat
 inline Mat updateQuat(const Mat& q, const Mat& dq) {
   Mat d = axisAngle2quat(dq);

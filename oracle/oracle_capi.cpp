@@ -11,7 +11,7 @@ using namespace orc;
 namespace {
 
 enum { DV_EUCLIDEAN_POINT = 0, DV_ROTATION_QUATERNION = 1, DV_SCALAR = 2, DV_EUCLIDEAN_DIRECTION = 3,
-       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6, DV_MATRIX_BASIC = 7 };
+       DV_SPLINE_COEFF = 4, DV_PROJECTION = 5, DV_DISTORTION = 6, DV_MATRIX_BASIC = 7, DV_HOMOGENEOUS_POINT = 8 };
 
 struct Problem {
   std::vector<std::unique_ptr<DesignVariable>> ownedDvs;
@@ -65,6 +65,7 @@ int orc_add_dv(void* h, int kind, const double* params, int n, int active, doubl
     case DV_SCALAR: d = new ScalarDv(params[0]); break;
     case DV_EUCLIDEAN_DIRECTION: d = new EuclideanDirection(params); break;
     case DV_PROJECTION: case DV_DISTORTION: d = new ParamVectorDv(params, n); break;
+    case DV_HOMOGENEOUS_POINT: d = new HomogeneousPointDv(params); break;
     default: throw std::runtime_error("unknown dv kind");
   }
   d->active = active != 0;
@@ -175,6 +176,23 @@ int orc_add_static_reprojection_batch(void* h, int cam, int nChain, const int* c
       P->terms.push_back(std::move(e));
     }
     ++P->nextShareGroup;
+  }
+  return 0;
+  ORC_CATCH(P, -1)
+}
+
+// estimateLandmarks: the point of the last n ReprojectionErrors becomes T * HomogeneousPointDv (CameraCalibrator.py:195-219)
+int orc_set_last_terms_landmarks(void* h, int n, const int* dvLm) {
+  Problem* P = (Problem*)h;
+  ORC_TRY(P)
+  if (n > (int)P->terms.size()) throw std::runtime_error("more landmarks than terms");
+  for (int k = 0; k < n; ++k) {
+    if (dvLm[k] < 0) continue;
+    ReprojectionError* e = dynamic_cast<ReprojectionError*>(P->terms[P->terms.size() - n + k].get());
+    if (!e) throw std::runtime_error("landmarks follow reprojection errors");
+    HomogeneousMultiplyNode* m = dynamic_cast<HomogeneousMultiplyNode*>(e->point.get());
+    if (!m) throw std::runtime_error("the point is not T * p");
+    m->r = HomP(new HomogeneousPointNode(P->dvAs<HomogeneousPointDv>(dvLm[k])));
   }
   return 0;
   ORC_CATCH(P, -1)

@@ -78,6 +78,9 @@ int probe_add_lidar_batch(void* h, int sp, int dtoff, int dq, int dt, int n, con
 int probe_add_motion_term(void* h, int sp, const double* W, int order) {
   Probe* pr = (Probe*)h; PR_TRY describeMotion(pr->P, sp, W, order); return 0; PR_CATCH(pr, -1)
 }
+int probe_set_last_batch_landmarks(void* h, int n, const int* dv) {
+  Probe* pr = (Probe*)h; PR_TRY describeLandmarks(pr->P, n, dv); return 0; PR_CATCH(pr, -1)
+}
 int probe_set_last_batch_sqrt_inv_r(void* h, int dim, int n, const double* S) {
   Probe* pr = (Probe*)h; PR_TRY describeSqrtInvR(pr->P, dim, n, S); return 0; PR_CATCH(pr, -1)
 }
@@ -232,6 +235,13 @@ int probe_term(void* h, int term, int useM, double* Jd, double* e, double* chi2)
     rolecol[F2_ROLE_QTC] = col(B.obs_dv_q[obs]); rolecol[F2_ROLE_TTC] = col(B.obs_dv_t[obs]);
     for (int j = 0; j < v.n_chain; ++j) { rolecol[F2_ROLE_CHAIN + 2 * j] = v.chain_q[j].col; rolecol[F2_ROLE_CHAIN + 2 * j + 1] = v.chain_t[j].col; }
     rolecol[F2_ROLE_PROJ] = v.cam.proj_col; rolecol[F2_ROLE_DIST] = v.cam.dist_col;
+    std::vector<int> lm_off;
+    if (!B.term_dv_lm.empty()) {
+      lm_off.assign(B.term_dv_lm.size(), -1);
+      const int lm = B.term_dv_lm[k];
+      if (lm >= 0) { lm_off[k] = P.dvs[lm].off; v.lm_scale = P.dvs[lm].scaling; rolecol[F2_ROLE_LM] = col(lm); }
+      v.lm_off = lm_off.data();
+    }
     f2_term(v, x, k, useM != 0, true, rolecol, Jd, JC, e, out);
   } else if (B.kind == KIND_GYRO_PRIOR) {
     GyroPriorBatchView v;

@@ -165,6 +165,10 @@ class OracleApi(object):
         W = _f64(W)
         self._chk(self.lib.orc_add_motion_term(self.h, C.c_int(spline), _d(W), C.c_int(order)))
 
+    def set_last_batch_landmarks(self, dv_landmark):
+        dv = _i32(dv_landmark)
+        self._chk(self.lib.orc_set_last_terms_landmarks(self.h, C.c_int(dv.size), _i(dv)))
+
     def set_last_batch_inv_r(self, invR):
         """ErrorTermFs::setInvR on the terms of the batch added last (oracle_unit_capi.hpp)"""
         invR = _f64(invR)

@@ -119,6 +119,10 @@ class ProbeApi(object):
         W = _f64(W)
         self._chk(self.L.probe_add_motion_term(self.h, C.c_int(sp), _d(W), C.c_int(order)))
 
+    def set_last_batch_landmarks(self, dv_landmark):
+        dv = _i32(dv_landmark)
+        self._chk(self.L.probe_set_last_batch_landmarks(self.h, C.c_int(dv.size), _i(dv)))
+
     def set_last_batch_inv_r(self, invR):
         """sqrtInvR from the product's own mc_compute_matrix_sqrt (the host library needs no GPU for it)"""
         from multical_amd._lib import load
