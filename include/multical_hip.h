@@ -284,6 +284,10 @@ int mc_device_info(mc_context* ctx, char* name, int name_len, int* n_cu, double*
  * BlockCholeskyLinearSystemSolver::initMatrixStructureImplementation passes to SparseBlockMatrix as cumulative block
  * sizes, BlockCholeskyLinearSystemSolver.cpp:47-54, shifted to start at 0) */
 int mc_get_block_bases(const mc_context* ctx, int* base);
+/* per block: the end of the support of the spline coefficient it belongs to, NaN for every other block (n_blocks entries).
+ * The coordinate along which the normal equations are banded; sorting by it eliminates a bias coefficient right after the
+ * last pose coefficient it is coupled to.  mc_cholesky_set_block_coordinates uses it. */
+int mc_get_block_times(const mc_context* ctx, double* t);
 
 /* sparse_block_matrix::LinearSolverCholmod<MatrixXd> (sparse_block_matrix/linear_solver_cholmod.h:55-112): analyze once
  * per structure, then factorize + solve per call.  The matrix is the upper-triangular scalar CCS that fillCCS emits;
@@ -295,6 +299,14 @@ mc_cholesky* mc_cholesky_create(void);
 void mc_cholesky_destroy(mc_cholesky* h);
 const char* mc_cholesky_last_error(const mc_cholesky* h);
 int mc_cholesky_analyze(mc_cholesky* h, int n, const int* Cp, const int* Ci, int n_blocks, const int* block_base);
+/* Optional, after mc_cholesky_analyze: a coordinate per block along which the matrix is banded (NaN: none) and the number
+ * of threads.  The blocks are cut into `threads` intervals; what couples two intervals, the blocks without a coordinate
+ * and the nearly dense blocks form a small top system, the rest falls into independent parts that are factorised and
+ * solved by one thread each (std::thread).  Without this call everything runs on the calling thread.  The symbolic work
+ * is done at the first mc_cholesky_factorize, on the blocks that hold a non-zero value there (the assembled pattern
+ * includes the numerically zero blocks of padded spline coefficients); it is redone if a later matrix has a value
+ * outside them. */
+int mc_cholesky_set_block_coordinates(mc_cholesky* h, const double* coord /* n_blocks */, int threads);
 int mc_cholesky_factorize(mc_cholesky* h, const double* Cx);
 int mc_cholesky_solve(mc_cholesky* h, const double* b, double* x);
 /* LinearSolverCholmod::solvePattern (linear_solver_cholmod.h:114-165), what BlockCholeskyLinearSystemSolver::

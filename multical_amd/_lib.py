@@ -99,10 +99,12 @@ class SolutionReturnValue(C.Structure):
 
 SIGNATURES.update({
     "mc_get_block_bases": (C.c_int, [_ctx, _ip]),
+    "mc_get_block_times": (C.c_int, [_ctx, _dp]),
     "mc_cholesky_create": (C.c_void_p, []),
     "mc_cholesky_destroy": (None, [C.c_void_p]),
     "mc_cholesky_last_error": (C.c_char_p, [C.c_void_p]),
     "mc_cholesky_analyze": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _ip]),
+    "mc_cholesky_set_block_coordinates": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "mc_cholesky_factorize": (C.c_int, [C.c_void_p, _dp]),
     "mc_cholesky_solve": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mc_cholesky_covariance_blocks": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(C.c_longlong), _dp]),

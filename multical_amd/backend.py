@@ -200,6 +200,12 @@ class HipApi(object):
         self._chk(self.lib.mc_get_block_bases(self.ctx, _ip(out)))
         return out
 
+    def block_times(self):
+        """per block: middle of the support of its spline coefficient, NaN for the other blocks"""
+        out = np.empty(self.n_blocks)
+        self._chk(self.lib.mc_get_block_times(self.ctx, _dp(out)))
+        return out
+
     def optimize(self, **kw):
         """Optimizer2::optimize in C++ (mc_optimize): keyword arguments are mc_optimizer_options fields.  Returns the
         mc_solution_return_value as a dict."""
@@ -354,6 +360,19 @@ class HipApi(object):
         return name.value.decode(), ncu.value, gib.value
 
 
+def host_threads():
+    """threads of the host factorisation: MC_CHOLESKY_THREADS, else the CPUs this process may run on, at most 16"""
+    import os
+    v = os.environ.get("MC_CHOLESKY_THREADS")
+    if v:
+        return max(1, int(v))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 # ------------------------------------------------------------------------------------------------
 class HostSparseCholesky(object):
     """sparse_block_matrix::LinearSolverCholmod::solve (linear_solver_cholmod.h:70-112) on the host: the C++ block
@@ -381,6 +400,15 @@ class HostSparseCholesky(object):
             raise BackendError(self.lib.mc_cholesky_last_error(self.h).decode())
         self._pattern = (n, Cp.ctypes.data, Cp.size, Ci.size)
         self._keep = (Cp, Ci)
+
+    def set_block_coordinates(self, coord, threads=None):
+        """time-axis dissection: independent parts factorised / solved by one thread each (see multical_hip.h)"""
+        coord = _f64(coord)
+        if threads is None:
+            threads = host_threads()
+        rc = self.lib.mc_cholesky_set_block_coordinates(self.h, _dp(coord), int(threads))
+        if rc != 0:
+            raise BackendError(self.lib.mc_cholesky_last_error(self.h).decode())
 
     def stats(self):
         nd, nnz, fl = C.c_int(), C.c_longlong(), C.c_double()
@@ -437,6 +465,7 @@ class HipBlockCholeskyLinearSystemSolver(object):
         n = self.api.j_cols
         self._diag_pos = self._Cp[1:] - 1          # last entry of every upper-triangular column = diagonal
         self._host.analyze(n, self._Cp, self._Ci, self.api.block_bases())
+        self._host.set_block_coordinates(self.api.block_times())
         self._diag = np.zeros(n)
         self._Cx = np.zeros(self.api.nnz)
         self._rhs = np.zeros(n)

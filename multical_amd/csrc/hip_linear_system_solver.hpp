@@ -195,9 +195,16 @@ class HipBlockCholeskyLinearSystemSolver : public LinearSystemSolver {
     blockBase_.assign(nBlocks_ + 1, 0);
     check(mc_get_block_bases(ctx_, blockBase_.data()));
     chol_.analyze(jCols_, Cp_.data(), Ci_.data(), nBlocks_, blockBase_.data());
+    setTimeAxis();
   }
 
  private:
+  // time-axis dissection of the host factorisation (host/block_cholesky.hpp): one thread per independent part
+  void setTimeAxis() {
+    std::vector<double> when(nBlocks_);
+    check(mc_get_block_times(ctx_, when.data()));
+    chol_.setBlockCoordinates(when.data(), hostCholeskyThreads());
+  }
   std::vector<int> Cp_, Ci_, blockBase_;
   std::vector<double> H_;
   BlockSparseCholesky chol_;
@@ -283,6 +290,11 @@ class HipSparseCholeskyLinearSystemSolver : public LinearSystemSolver {
     std::vector<int> base(nBlocks_ + 1, 0);
     check(mc_get_block_bases(ctx_, base.data()));
     chol_.analyze(jCols_, Cp_.data(), Ci_.data(), nBlocks_, base.data());
+    {
+      std::vector<double> when(nBlocks_);
+      check(mc_get_block_times(ctx_, when.data()));
+      chol_.setBlockCoordinates(when.data(), hostCholeskyThreads());
+    }
   }
 
  private:

@@ -69,7 +69,7 @@ class NormalEquations {
   virtual void adopt() = 0;                                           // the last trial's linearisation becomes the system
   virtual bool step(double damping, std::vector<double>& dx) = 0;     // (H + damping^2 I) dx = rhs on the adopted system
   virtual const std::vector<double>& gradient() const = 0;            // rhs = -J^T e of the adopted system
-  virtual void factorStats(double& nnz, double& flops) const { nnz = flops = 0; }
+  virtual void factorStats(double& nnz, double& flops) { nnz = flops = 0; }
 };
 
 // The fused GPU path: two device systems (adopted / trial), one pinned host image for the factorisation.
@@ -91,6 +91,11 @@ class FusedBlockEquations : public NormalEquations {
     ok(mc_get_pattern(ctx_, colEnd_.data(), rowIdx.data()));
     ok(mc_get_block_bases(ctx_, base.data()));
     chol_.analyze(n_, colEnd_.data(), rowIdx.data(), blocks, base.data());
+    {
+      std::vector<double> when(blocks);
+      ok(mc_get_block_times(ctx_, when.data()));
+      chol_.setBlockCoordinates(when.data(), hostCholeskyThreads());   // time-axis dissection: one thread per part
+    }
     for (int k = 0; k < 2; ++k) {
       detail::hipOk(hipMalloc((void**)&dH_[k], sizeof(double) * (size_t)nnz_), "hipMalloc(system values)");
       detail::hipOk(hipMalloc((void**)&dG_[k], sizeof(double) * (size_t)n_), "hipMalloc(gradient)");
@@ -126,7 +131,7 @@ class FusedBlockEquations : public NormalEquations {
     return good;
   }
   const std::vector<double>& gradient() const override { return g_; }
-  void factorStats(double& nnz, double& flops) const override { nnz = (double)chol_.stats().nnz_factor; flops = chol_.stats().flops; }
+  void factorStats(double& nnz, double& flops) override { nnz = (double)chol_.stats().nnz_factor; flops = chol_.stats().flops; }
 
  private:
   void ok(int rc) const { if (rc < 0) throw Exception(mc_last_error(ctx_)); }

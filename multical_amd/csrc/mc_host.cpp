@@ -28,6 +28,10 @@ int mc_cholesky_analyze(mc_cholesky* h, int n, const int* Cp, const int* Ci, int
   try { h->chol.analyze(n, Cp, Ci, n_blocks, block_base); return 0; }
   catch (const std::exception& e) { h->err = e.what(); return -1; }
 }
+int mc_cholesky_set_block_coordinates(mc_cholesky* h, const double* coord, int threads) {
+  try { h->chol.setBlockCoordinates(coord, threads); return 0; }
+  catch (const std::exception& e) { h->err = e.what(); return -1; }
+}
 int mc_cholesky_factorize(mc_cholesky* h, const double* Cx) {
   try { return h->chol.factorize(Cx) ? 0 : 1; }
   catch (const std::exception& e) { h->err = e.what(); return -1; }
@@ -42,14 +46,14 @@ int mc_cholesky_covariance_blocks(mc_cholesky* h, int n_pairs, const int* block_
   catch (const std::exception& e) { h->err = e.what(); return -1; }
 }
 int mc_cholesky_stats(const mc_cholesky* h, int* n_dense_blocks, long long* nnz_factor, double* flops) {
-  const BlockSparseCholesky::Stats& s = h->chol.stats();
+  const BlockSparseCholesky::Stats& s = const_cast<mc_cholesky*>(h)->chol.stats();
   if (n_dense_blocks) *n_dense_blocks = s.n_dense_blocks;
   if (nnz_factor) *nnz_factor = s.nnz_factor;
   if (flops) *flops = s.flops;
   return 0;
 }
 int mc_cholesky_block_permutation(const mc_cholesky* h, int* perm) {
-  const std::vector<int>& p = h->chol.blockPermutation();
+  const std::vector<int>& p = const_cast<mc_cholesky*>(h)->chol.blockPermutation();
   std::memcpy(perm, p.data(), sizeof(int) * p.size());
   return (int)p.size();
 }

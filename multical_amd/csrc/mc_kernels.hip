@@ -2192,6 +2192,17 @@ int mc_get_block_bases(const mc_context* ctx, int* base) {
   base[ctx->P.n_blocks] = c;
   return 0;
 }
+int mc_get_block_times(const mc_context* ctx, double* t) {
+  if (!ctx->P.finalized || !t) return -1;
+  const Problem& P = ctx->P;
+  for (int b = 0; b < P.n_blocks; ++b) t[b] = std::nan("");
+  for (const SplineRec& s : P.splines)
+    for (int i = 0; i < s.n_coeff; ++i) {
+      const int b = P.dvs[s.first_dv + i].block;
+      if (b >= 0) t[b] = P.knots[s.knots_off + i + s.order];   // end of the coefficient's support
+    }
+  return 0;
+}
 int mc_get_pattern(const mc_context* ctx, int* Cp, int* Ci) {
   if (!ctx->P.finalized) return -1;
   if (Cp) std::memcpy(Cp, ctx->P.Cp.data(), sizeof(int) * ctx->P.Cp.size());

@@ -110,6 +110,23 @@ int probe_get_pattern(void* h, int* Cp, int* Ci) {
   std::memcpy(Ci, P.Ci.data(), sizeof(int) * P.Ci.size());
   return 0;
 }
+int probe_get_block_bases(void* h, int* base) {
+  Problem& P = ((Probe*)h)->P;
+  int c = 0;
+  for (int b = 0; b < P.n_blocks; ++b) { base[b] = c; c += P.block_dim[b]; }
+  base[P.n_blocks] = c;
+  return 0;
+}
+int probe_get_block_times(void* h, double* t) {
+  Problem& P = ((Probe*)h)->P;
+  for (int b = 0; b < P.n_blocks; ++b) t[b] = std::nan("");
+  for (const SplineRec& s : P.splines)
+    for (int i = 0; i < s.n_coeff; ++i) {
+      const int b = P.dvs[s.first_dv + i].block;
+      if (b >= 0) t[b] = P.knots[s.knots_off + i + s.order];
+    }
+  return 0;
+}
 // number of groups kept by this rank / total (sharding checks)
 int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {
   Problem& P = ((Probe*)h)->P;

@@ -151,6 +151,16 @@ class ProbeApi(object):
         self.L.probe_get_pattern(self.h, _i(Cp), _i(Ci))
         return Cp, Ci
 
+    def block_bases(self):
+        out = np.empty(self.n_blocks + 1, np.int32)
+        self.L.probe_get_block_bases(self.h, _i(out))
+        return out
+
+    def block_times(self):
+        out = np.empty(self.n_blocks)
+        self.L.probe_get_block_times(self.h, _d(out))
+        return out
+
     def term(self, t, use_mest=True):
         J = np.zeros((6, self.j_cols))
         e = np.zeros(6)

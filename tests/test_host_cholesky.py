@@ -179,3 +179,94 @@ def test_covariance_blocks_match_the_dense_inverse():
         blk = out[off[k]:off[k + 1]].reshape(base[i + 1] - base[i], base[j + 1] - base[j])
         want = Pinv[base[i]:base[i + 1], base[j]:base[j + 1]]
         assert np.abs(blk - want).max() <= 1e-9 * np.abs(Pinv).max()
+
+
+# ---- time-axis dissection (independent parts, one thread each) and the numerical pattern ------------------------------
+def _coords(base, n_band):
+    """band blocks get their position, the global blocks none"""
+    t = np.full(len(base) - 1, np.nan)
+    t[:n_band] = np.arange(n_band, dtype=float)
+    return t
+
+
+@pytest.mark.parametrize("threads", [1, 2, 4, 7])
+def test_dissection_matches_dense(threads):
+    rng = np.random.default_rng(31 + threads)
+    n_band = 700
+    U, base, H = arrowhead_problem(rng, n_band=n_band)
+    c = Chol()
+    c.analyze(U, base)
+    assert c.lib.mc_cholesky_set_block_coordinates(c.h, _dp(_coords(base, n_band)), threads) == 0
+    assert c.factorize(U.data) == 0
+    b = rng.standard_normal(U.shape[0])
+    xr = np.linalg.solve(H, b)
+    assert np.abs(c.solve(b) - xr).max() <= 1e-9 * np.abs(xr).max()
+    perm = np.zeros(len(base) - 1, np.int32)
+    assert c.lib.mc_cholesky_block_permutation(c.h, _ip(perm)) == len(perm)
+    assert sorted(perm.tolist()) == list(range(len(perm)))
+    # new values, same structure; then a matrix that is not positive definite; then a good one again
+    H2 = H + np.diag(rng.random(H.shape[0]) * 3.0)
+    v2 = H2[U.indices, np.repeat(np.arange(U.shape[0]), np.diff(U.indptr))]
+    assert c.factorize(v2) == 0
+    assert np.abs(c.solve(b) - np.linalg.solve(H2, b)).max() <= 1e-9 * np.abs(xr).max()
+    bad = v2.copy()
+    bad[U.indptr[1:][U.shape[0] // 2] - 1] = -5.0
+    assert c.factorize(bad) == 1
+    assert c.factorize(v2) == 0
+
+
+def test_dissection_covariance_blocks():
+    rng = np.random.default_rng(77)
+    n_band = 400
+    U, base, H = arrowhead_problem(rng, n_band=n_band)
+    c = Chol()
+    c.analyze(U, base)
+    assert c.lib.mc_cholesky_set_block_coordinates(c.h, _dp(_coords(base, n_band)), 4) == 0
+    assert c.factorize(U.data) == 0
+    nb = len(base) - 1
+    pairs = [(nb - 1, nb - 1), (5, 5), (200, nb - 2), (399, 398)]
+    bi, bj = np.array([p[0] for p in pairs], np.int32), np.array([p[1] for p in pairs], np.int32)
+    sizes = (base[bi + 1] - base[bi]).astype(np.int64) * (base[bj + 1] - base[bj])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    out = np.zeros(int(off[-1]))
+    assert c.lib.mc_cholesky_covariance_blocks(c.h, len(pairs), _ip(bi), _ip(bj), off.ctypes.data_as(C.POINTER(C.c_longlong)), _dp(out)) == 0
+    Pinv = np.linalg.inv(H)
+    for k, (i, j) in enumerate(pairs):
+        blk = out[off[k]:off[k + 1]].reshape(base[i + 1] - base[i], base[j + 1] - base[j])
+        assert np.abs(blk - Pinv[base[i]:base[i + 1], base[j]:base[j + 1]]).max() <= 1e-9 * np.abs(Pinv).max()
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_numerically_zero_blocks_are_left_out_and_come_back(threads):
+    """The structurally present, numerically zero blocks (padded spline coefficients) do not enter the factor; when one of
+    them becomes non-zero in a later matrix the structure grows and the answer is still right."""
+    rng = np.random.default_rng(41)
+    n_band = 500
+    U, base, H = arrowhead_problem(rng, n_band=n_band, extra_pairs=300)
+    full = Chol()
+    full.analyze(U, base)
+    nnz_full = full.stats()[1]                      # before any factorize: the structure of the whole pattern
+    c = Chol()
+    c.analyze(U, base)
+    assert c.lib.mc_cholesky_set_block_coordinates(c.h, _dp(_coords(base, n_band)), threads) == 0
+    assert c.factorize(U.data) == 0
+    assert c.stats()[1] < nnz_full                  # the zero blocks were dropped
+    b = rng.standard_normal(U.shape[0])
+    xr = np.linalg.solve(H, b)
+    assert np.abs(c.solve(b) - xr).max() <= 1e-9 * np.abs(xr).max()
+    # switch on a stored-but-zero block far from the diagonal
+    cols = np.repeat(np.arange(U.shape[0]), np.diff(U.indptr))
+    zero = np.nonzero((U.data == 0.0) & (cols - U.indices > 40))[0]
+    assert zero.size > 0
+    k = zero[zero.size // 2]
+    i, j = U.indices[k], cols[k]
+    H3 = H.copy()
+    H3[i, j] = H3[j, i] = 0.25
+    H3[i, i] += 1.0; H3[j, j] += 1.0
+    v3 = H3[U.indices, cols]
+    assert c.factorize(v3) == 0
+    x3 = np.linalg.solve(H3, b)
+    assert np.abs(c.solve(b) - x3).max() <= 1e-9 * np.abs(x3).max()
+    # and back on the first matrix: blocks are never dropped again, the result is unchanged
+    assert c.factorize(U.data) == 0
+    assert np.abs(c.solve(b) - xr).max() <= 1e-9 * np.abs(xr).max()
