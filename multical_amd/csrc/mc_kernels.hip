@@ -489,16 +489,33 @@ __device__ __forceinline__ int slot_lookup(const DevCommon& dc, int rb, int cb) 
   return (lo < end && dc.pat_rows[lo] == rb) ? dc.pat_cp0[cb] + dc.pat_roff[lo] : -1;
 }
 
+#ifndef MC_GATHER_UNROLL
+#define MC_GATHER_UNROLL 1
+#endif
+#ifndef MC_STREAM_OCC
+#define MC_STREAM_OCC 1
+#endif
+#ifndef MC_LIDAR_OCC
+#define MC_LIDAR_OCC 3   // compact rows: 47 KB of LDS per workgroup, 3 per CU; 168 VGPRs cost 196 B of scratch per lane and still win (0.468 -> 0.427 ms)
+#endif
 template <class View> struct StreamTraits;
 template <> struct StreamTraits<LidarBatchView> {
-  enum { D = 1 };
+  // CO = columns the coefficient part of a row takes in the LDS tile: the lidar row is rank one in the coefficients
+  // (w_i * B), stored as [B 6 | w 6]
+  enum { D = 1, CO = 12, OCC = MC_LIDAR_OCC };
+  static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
+    const double2* q = reinterpret_cast<const double2*>(row);
+    const double2 b01 = q[0], b23 = q[1], b45 = q[2];
+    const double w = row[6 + o];
+    v[0] = w * b01.x; v[1] = w * b01.y; v[2] = w * b23.x; v[3] = w * b23.y; v[4] = w * b45.x; v[5] = w * b45.y;
+  }
   // returns beta0 (>= 0) or -1 after setting *st
   static __device__ __forceinline__ int eval(const LidarBatchView& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int term_lo, int term_nbuf,
                                              double* J, int ld, double* e, TermOut& out, int* st) {
     int rc[MC_MAX_ROLES];
 #pragma unroll
-    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? 36 + of[4 + r] : -1;
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? CO + of[4 + r] : -1;
     int beta0 = 0;
     rc[F5_ROLE_COEF] = -1;
     if (pose_nb > 0) {
@@ -510,18 +527,23 @@ template <> struct StreamTraits<LidarBatchView> {
       beta0 = seg - pose_lo;
       rc[F5_ROLE_COEF] = 0;
     }
-    if (!f5_term(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    if (!f5_term<true>(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     return beta0;
   }
 };
 template <> struct StreamTraits<ImuBatchView> {
-  enum { D = 3 };
+  enum { D = 3, CO = 36, OCC = MC_STREAM_OCC };
+  static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
+    const double2* q = reinterpret_cast<const double2*>(row + 6 * o);   // 16-byte aligned: ld and 6 o are even
+    const double2 a = q[0], b2 = q[1], c = q[2];
+    v[0] = a.x; v[1] = a.y; v[2] = b2.x; v[3] = b2.y; v[4] = c.x; v[5] = c.y;
+  }
   static __device__ __forceinline__ int eval(const ImuBatchView& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int, int,
                                              double* J, int ld, double* e, TermOut& out, int* st) {
     int rc[MC_MAX_ROLES];
 #pragma unroll
-    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? 36 + of[4 + r] : -1;
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? CO + of[4 + r] : -1;
     const double t = b.t[u];
     if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     int beta0 = 0;
@@ -537,13 +559,18 @@ template <> struct StreamTraits<ImuBatchView> {
 };
 
 template <> struct StreamTraits<ImuSmBatchView> {
-  enum { D = 3 };
+  enum { D = 3, CO = 36, OCC = MC_STREAM_OCC };
+  static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
+    const double2* q = reinterpret_cast<const double2*>(row + 6 * o);   // 16-byte aligned: ld and 6 o are even
+    const double2 a = q[0], b2 = q[1], c = q[2];
+    v[0] = a.x; v[1] = a.y; v[2] = b2.x; v[3] = b2.y; v[4] = c.x; v[5] = c.y;
+  }
   static __device__ __forceinline__ int eval(const ImuSmBatchView& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int, int,
                                              double* J, int ld, double* e, TermOut& out, int* st) {
     int rc[MC_MAX_ROLES];
 #pragma unroll
-    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? 36 + of[4 + r] : -1;
+    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? CO + of[4 + r] : -1;
     const double t = b.t[u];
     if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     int beta0 = 0;
@@ -558,17 +585,11 @@ template <> struct StreamTraits<ImuSmBatchView> {
   }
 };
 
-#ifndef MC_GATHER_UNROLL
-#define MC_GATHER_UNROLL 1
-#endif
-#ifndef MC_STREAM_OCC
-#define MC_STREAM_OCC 1
-#endif
 template <class View, bool BUILD>
-__global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
+__global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
                                                 const ChunkRec* __restrict__ chunks, StreamDims dm, int jpart_base) {
   extern __shared__ double smem[];
-  constexpr int D = StreamTraits<View>::D;
+  constexpr int D = StreamTraits<View>::D, CO = StreamTraits<View>::CO;
   const int tid = threadIdx.x;
   const ChunkRec ch = chunks[blockIdx.x];
   const View b = batches[ch.batch].v;
@@ -620,7 +641,7 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
 #pragma unroll
       for (int r = 0; r < D; ++r) {
         if (dc.e) dc.e[b.row_base + D * u + r] = -e[r];
-        if (build) Jrow[r * ld + 36 + G] = e[r];
+        if (build) Jrow[r * ld + CO + G] = e[r];
       }
       if (build) {
         beta0[tid] = b0;
@@ -707,14 +728,12 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
       for (int k = fge[max(0, bj - 5)]; k < k1; ++k) {
         const int o = bi - beta0[k];
         if ((unsigned)o > (unsigned)(5 - d)) continue;   // a failed term (all-zero row)
-        const double* px = rows + (size_t)k * rstride + 6 * o;
+        const double* px = rows + (size_t)k * rstride;
 #pragma unroll
         for (int r = 0; r < D; ++r) {
-          const double2* qx = reinterpret_cast<const double2*>(px + r * ld);   // 16-byte aligned: ld and 6 o are even
-          const double2* qy = reinterpret_cast<const double2*>(px + r * ld + 6 * d);
-          const double2 x01 = qx[0], x23 = qx[1], x45 = qx[2], y01 = qy[0], y23 = qy[1], y45 = qy[2];
-          const double xv[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
-          const double yv[6] = {y01.x, y01.y, y23.x, y23.y, y45.x, y45.y};
+          double xv[6], yv[6];
+          StreamTraits<View>::coef6(px + r * ld, o, xv);
+          StreamTraits<View>::coef6(px + r * ld, o + d, yv);
 #pragma unroll
           for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -769,10 +788,10 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
         const double* px = rows + (size_t)k * rstride;
 #pragma unroll
         for (int r = 0; r < D; ++r) {
-          const double2* qx = reinterpret_cast<const double2*>(px + r * ld + 6 * o);
-          const double2* qy = reinterpret_cast<const double2*>(px + r * ld + 36 + GT * gt);   // columns past G: zeroed padding
-          const double2 x01 = qx[0], x23 = qx[1], x45 = qx[2], y01 = qy[0], y23 = qy[1];
-          const double xv[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+          double xv[6];
+          StreamTraits<View>::coef6(px + r * ld, o, xv);
+          const double2* qy = reinterpret_cast<const double2*>(px + r * ld + CO + GT * gt);   // columns past G: zeroed padding
+          const double2 y01 = qy[0], y23 = qy[1];
           const double yv[GT] = {y01.x, y01.y, y23.x, y23.y};
 #pragma unroll
           for (int i = 0; i < 6; ++i)
@@ -834,7 +853,7 @@ __global__ __launch_bounds__(256, BUILD ? MC_STREAM_OCC : 1) void k_stream(const
     const int g2 = idx / G1, g1 = idx - g2 * G1;
     if (g1 > g2 || g1 == G) continue;
     double acc = 0.0;
-    const double* row = rows + 36;
+    const double* row = rows + CO;
 #pragma unroll 8
     for (int k = 0; k < T * D; ++k, row += ld) acc += row[g1] * row[g2];   // unrolled: independent LDS reads in flight
     if (MC_MODE(dc) != 1) { if (acc == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
@@ -1813,7 +1832,8 @@ void mc_context::uploadStructure() {
       L.n_items = (int)chunks[l].size();
       L.n_jpart = L.n_items;
       StreamDims& dm = L.dims;
-      dm.ld = 36 + ((dm.maxG + 1 + 3) / 4) * 4;   // 36 live coefficient columns + (other columns + residual) padded to whole 4-column tiles
+      // coefficient columns (36 live ones; lidar: 12, rank-one form) + (other columns + residual) padded to whole 4-column tiles
+      dm.ld = (l == LAUNCH_LIDAR ? 12 : 36) + ((dm.maxG + 1 + 3) / 4) * 4;
       const int dim = l == LAUNCH_LIDAR ? 1 : 3;
       size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + dm.maxTab + (size_t)dm.maxG * dm.maxNb + 4;
       L.lds_bytes = (int)((size_t)dm.maxT * dim * dm.ld * sizeof(double) + ints * sizeof(int) + 16);

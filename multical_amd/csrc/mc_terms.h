@@ -274,6 +274,10 @@ struct LidarBatchView {
   int mest; double mest_a;
   int n_terms, row_base, term_base_global;
 };
+// COMPACT: the 36 coefficient columns of the row are w_i * B (rank one), so only B (6 values, at rolecol[COEF]) and the 6
+// basis weights (behind it) are written; the stream kernel's Gram forms w_i w_j B^T B from them (12 columns instead of 36
+// in the LDS tile)
+template <bool COMPACT = false>
 MC_HD bool f5_term(const LidarBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol,
                    double* J, int ld, double* e, TermOut& out) {
   double t = b.t[k] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
@@ -321,9 +325,15 @@ MC_HD bool f5_term(const LidarBatchView& b, const double* x, int k, bool useM, b
   // lhs T_w_b: time-offset spline node
   double B[6];
   chain_JT(u2, v2, ps.c, ps.S, B);
-  if (rolecol[F5_ROLE_COEF] >= 0)
-    for (int i = 0; i < S6; ++i)
-      for (int c = 0; c < 6; ++c) J[rolecol[F5_ROLE_COEF] + 6 * i + c] = ps.w[0][i] * B[c] * b.coef_scale;
+  if (rolecol[F5_ROLE_COEF] >= 0) {
+    if (COMPACT) {
+      for (int c = 0; c < 6; ++c) J[rolecol[F5_ROLE_COEF] + c] = B[c] * b.coef_scale;
+      for (int i = 0; i < S6; ++i) J[rolecol[F5_ROLE_COEF] + 6 + i] = ps.w[0][i];
+    } else {
+      for (int i = 0; i < S6; ++i)
+        for (int c = 0; c < 6; ++c) J[rolecol[F5_ROLE_COEF] + 6 * i + c] = ps.w[0][i] * B[c] * b.coef_scale;
+    }
+  }
   if (rolecol[F5_ROLE_TOFF] >= 0) {
     double jd = 0;
     for (int c = 0; c < 6; ++c) jd += B[c] * ps.cd[c];

@@ -255,6 +255,28 @@ def test_time_offset_buffer_exceeded_is_reported(small_problem):
         g.evaluate_error(True)
 
 
+def test_solver_classes_throw_before_consuming_a_failed_build(small_problem):
+    """When a term fails (status != 0) Cx / rhs are undefined (multical_hip.h): the solver classes must raise from
+    buildSystem / evaluateError instead of handing a partial system to the factorisation."""
+    from multical_amd.backend import BackendError, HipBlockCholeskyLinearSystemSolver
+    g, ids = _hip(small_problem["spec"])
+    s = HipBlockCholeskyLinearSystemSolver(g)
+    s.initMatrixStructure(True)
+    s.evaluateError()
+    s.buildSystem()                                    # fine at the initial state
+    b, c = g.dv_block(ids[small_problem["H"]["cams"][0]["toff"]])
+    dx = np.zeros(g.j_cols)
+    dx[c] = 0.08
+    g.apply_update(dx)
+    with pytest.raises(BackendError, match="Buffer Exceeded"):
+        s.buildSystem()
+    with pytest.raises(BackendError, match="Buffer Exceeded"):
+        s.evaluateError()
+    g.revert_update()
+    s.evaluateError()
+    s.buildSystem()                                    # and usable again after the revert
+
+
 def test_levenberg_marquardt_matches_oracle():
     """Optimizer2 + LM policy on the HIP backend vs the oracle's restatement of the same loop (including the
     lambda^2 / lambda un-augment quirk and the no-rebuild-after-rejection rule): same accepted / rejected step sequence,
