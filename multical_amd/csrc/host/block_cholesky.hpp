@@ -520,7 +520,7 @@ class BlockSparseCholesky {
   // values -> panels; false if a non-zero value falls outside the kept blocks
   bool scatter(const double* Cx) {
     const size_t nnz = amap_.size(), nl = Lx_.size();
-    const int T = std::max(1, threads_);
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, nnz / 200000 + 1));   // small systems: not worth the threads
     std::vector<char> inside(T, 1);
     auto zero = [&](int t) { std::fill(Lx_.begin() + nl * t / T, Lx_.begin() + nl * (t + 1) / T, 0.0); };
     auto fill = [&](int t) {
