@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
   const int lane = tid & 63, wave = tid >> 6;
   double* strip = wstrip[wave];
   const int rstride = D * ld;
+  const int smax = max(nb - S6, 0);   // last possible first live block
   // turn6: every lane hands in 6 values; emit(p, v) receives element e = 64 p + lane (p = 0..5) of the wave's 384 values
   // (element 6 l + i = value i of lane l).  Half a wave at a time through the 32 x 6 strip; LDS accesses of one wave
   // execute in program order, the barriers only pin the compiler's schedule.
@@ -723,21 +724,24 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc[i][j] = 0.0;
     if (t < nband && bi >= 0 && band_slot[bj * 6 + d] >= 0) {
-      const int k1 = fge[bi + 1];
+      // by segment: the terms whose live window starts at block sg are the run [fge[sg], fge[sg + 1]) (a failed term inside
+      // has an all-zero row), so the position o = bi - sg of the tile in the row is known without reading beta0 and the
+      // LDS reads of consecutive terms do not depend on one another
+      for (int sg = max(0, bj - 5); sg <= bi; ++sg) {
+        const int o = bi - sg, k1 = fge[sg + 1];
+        const double* px = rows + (size_t)fge[sg] * rstride;
 #pragma unroll MC_GATHER_UNROLL
-      for (int k = fge[max(0, bj - 5)]; k < k1; ++k) {
-        const int o = bi - beta0[k];
-        if ((unsigned)o > (unsigned)(5 - d)) continue;   // a failed term (all-zero row)
-        const double* px = rows + (size_t)k * rstride;
+        for (int k = fge[sg]; k < k1; ++k, px += rstride) {
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
-          double xv[6], yv[6];
-          StreamTraits<View>::coef6(px + r * ld, o, xv);
-          StreamTraits<View>::coef6(px + r * ld, o + d, yv);
+          for (int r = 0; r < D; ++r) {
+            double xv[6], yv[6];
+            StreamTraits<View>::coef6(px + r * ld, o, xv);
+            StreamTraits<View>::coef6(px + r * ld, o + d, yv);
 #pragma unroll
-          for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] += xv[i] * yv[j];
+              for (int j = 0; j < 6; ++j) acc[i][j] += xv[i] * yv[j];
+          }
         }
       }
     }
@@ -780,12 +784,11 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
 #pragma unroll
       for (int j = 0; j < GT; ++j) acc[i][j] = 0.0;
     if (t < narrow) {
-      const int k1 = fge[bi + 1];
+      for (int sg = max(0, bi - 5); sg <= min(bi, smax); ++sg) {
+        const int o = bi - sg, k1 = fge[sg + 1];
+        const double* px = rows + (size_t)fge[sg] * rstride;
 #pragma unroll MC_GATHER_UNROLL
-      for (int k = fge[max(0, bi - 5)]; k < k1; ++k) {
-        const int o = bi - beta0[k];
-        if ((unsigned)o > 5u) continue;
-        const double* px = rows + (size_t)k * rstride;
+        for (int k = fge[sg]; k < k1; ++k, px += rstride) {
 #pragma unroll
         for (int r = 0; r < D; ++r) {
           double xv[6];
@@ -797,6 +800,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
           for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j < GT; ++j) acc[i][j] += xv[i] * yv[j];
+        }
         }
       }
     }
