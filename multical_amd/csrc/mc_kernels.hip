@@ -503,6 +503,7 @@ template <> struct StreamTraits<LidarBatchView> {
   // CO = columns the coefficient part of a row takes in the LDS tile: the lidar row is rank one in the coefficients
   // (w_i * B), stored as [B 6 | w 6]
   enum { D = 1, CO = 12, OCC = MC_LIDAR_OCC };
+  static __device__ __forceinline__ int biasColumns(const LidarBatchView&, const int*, int& n) { n = 0; return 0; }
   static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
     const double2* q = reinterpret_cast<const double2*>(row);
     const double2 b01 = q[0], b23 = q[1], b45 = q[2];
@@ -533,6 +534,12 @@ template <> struct StreamTraits<LidarBatchView> {
 };
 template <> struct StreamTraits<ImuBatchView> {
   enum { D = 3, CO = 36, OCC = MC_STREAM_OCC };
+  // first local "other" column and number of columns of the bias (spline window or static point); n = 0: no shortcut
+  template <class V> static __device__ __forceinline__ int biasColumns(const V& b, const int* of, int& n) {
+    const int c0 = of[4 + IMU_ROLE_BIAS];
+    n = (c0 >= 0 && b.S == nullptr) ? (b.bias.order > 0 ? 3 * of[3] : 3) : 0;
+    return c0;
+  }
   static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
     const double2* q = reinterpret_cast<const double2*>(row + 6 * o);   // 16-byte aligned: ld and 6 o are even
     const double2 a = q[0], b2 = q[1], c = q[2];
@@ -560,6 +567,12 @@ template <> struct StreamTraits<ImuBatchView> {
 
 template <> struct StreamTraits<ImuSmBatchView> {
   enum { D = 3, CO = 36, OCC = MC_STREAM_OCC };
+  // first local "other" column and number of columns of the bias (spline window or static point); n = 0: no shortcut
+  template <class V> static __device__ __forceinline__ int biasColumns(const V& b, const int* of, int& n) {
+    const int c0 = of[4 + IMU_ROLE_BIAS];
+    n = (c0 >= 0 && b.S == nullptr) ? (b.bias.order > 0 ? 3 * of[3] : 3) : 0;
+    return c0;
+  }
   static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
     const double2* q = reinterpret_cast<const double2*>(row + 6 * o);   // 16-byte aligned: ld and 6 o are even
     const double2 a = q[0], b2 = q[1], c = q[2];
@@ -829,6 +842,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
   }
   MC_MARK(pslot + 4);   // coefficient x other
   // (iii) other x other (upper triangle) and the other part of rhs
+  int bias_n_ = 0;
   auto oo_flush = [&](int g1, int g2, double acc) {
     if (g1 > g2 || g1 >= G || g2 > G || acc == 0.0) return;
     const int o1 = ocolblk[g1], s1 = g1 - oinfo[3 * o1 + 1];
@@ -853,13 +867,31 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
     }
   };
   const int G1 = G + 1;
+  const int bias_0 = StreamTraits<View>::biasColumns(b, of, bias_n_);
+  const int bias_n = bias_n_;
   for (int idx = tid; idx < G1 * G1; idx += 256) {
     const int g2 = idx / G1, g1 = idx - g2 * G1;
     if (g1 > g2 || g1 == G) continue;
+    // IMU rows: residual row r holds the bias columns of component r only (the bias Jacobian is w_i I), so a product with
+    // a bias column runs over every third row, and two bias columns of different components never meet.  Not with a
+    // general sqrtInvR, which mixes the rows.
+    int only = -1;
+    if (D == 3 && bias_n > 0) {
+      const int c1 = (unsigned)(g1 - bias_0) < (unsigned)bias_n ? (g1 - bias_0) % 3 : -1;
+      const int c2 = (unsigned)(g2 - bias_0) < (unsigned)bias_n ? (g2 - bias_0) % 3 : -1;
+      if (c1 >= 0 && c2 >= 0 && c1 != c2) continue;
+      only = c1 >= 0 ? c1 : c2;
+    }
     double acc = 0.0;
-    const double* row = rows + CO;
+    if (only >= 0) {
+      const double* row = rows + CO + only * ld;
 #pragma unroll 8
-    for (int k = 0; k < T * D; ++k, row += ld) acc += row[g1] * row[g2];   // unrolled: independent LDS reads in flight
+      for (int k = 0; k < T; ++k, row += D * ld) acc += row[g1] * row[g2];
+    } else {
+      const double* row = rows + CO;
+#pragma unroll 8
+      for (int k = 0; k < T * D; ++k, row += ld) acc += row[g1] * row[g2];   // unrolled: independent LDS reads in flight
+    }
     if (MC_MODE(dc) != 1) { if (acc == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
     oo_flush(g1, g2, acc);
   }
