@@ -25,6 +25,9 @@
 #include <thread>
 #include <utility>
 #include <vector>
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
 
 namespace multical_amd {
 
@@ -43,6 +46,7 @@ class BlockSparseCholesky {
     long long nnz_factor = 0;     // scalar entries stored in the panels
     double flops = 0;             // of one numeric factorisation
     int symbolic_passes = 0;      // 1 + the number of times the numerical pattern grew
+    int n_panels = 0;             // block columns of the factor (neighbouring blocks with one structure share a panel)
     int n_parts = 0, n_top_blocks = 0;   // independent parts (threads) and the blocks left for the serial top
   };
 
@@ -103,18 +107,18 @@ class BlockSparseCholesky {
     const auto t0 = now();
     if (!symbolic_) { markKept(Cx); buildSymbolic(); }
     const auto t1 = now();
-    if (!scatter(Cx)) {          // a value outside the kept blocks: grow the structure
+    if (!checkDropped(Cx)) {     // a value outside the kept blocks: grow the structure
       markKept(Cx);
       buildSymbolic();
-      scatter(Cx);
     }
     const auto t2 = now();
-    next_.assign(nb_, -1);
-    pos_.assign(nb_, 0);
+    next_.assign(np_, -1);
+    pos_.assign(np_, 0);
     if (part_start_.empty()) {
-      Work ws(nb_, (size_t)max_m_ * max_d_, 0);
-      for (int j = 0; j < nb_; ++j) {
+      Work ws(np_, nb_, 0);
+      for (int j = 0; j < np_; ++j) {
         double* P = Lx_.data() + valptr_[j];
+        preparePanel(j, Cx);
         applyUpdates(j, P, ws);
         if (!factorPanel(P, dim_[j], m_[j])) return false;
         link(j, ws.head);
@@ -125,22 +129,36 @@ class BlockSparseCholesky {
     // the independent parts, one thread each: their own columns, then their contributions to the top's panels (into a
     // private copy: the top's columns receive updates from every part)
     const int P = (int)part_start_.size() - 1;
-    const long long top0 = valptr_[top_start_];
-    const size_t top_size = (size_t)(valptr_[nb_] - top0);
-    std::vector<Work> work;
-    work.reserve(P);
-    for (int t = 0; t < P; ++t) work.emplace_back(nb_, (size_t)max_m_ * max_d_, top_size);
+    const long long top0 = valptr_[top_start_panel_];
+    const size_t top_size = (size_t)(valptr_[np_] - top0);
+    // per-part scratch, kept between factorisations (first-touch page faults of 16 private top images cost more than
+    // the factorisation of a part); each part clears its own image
+    std::vector<Work>& work = work_;
+    if ((int)work.size() != P || work[0].top.size() != top_size || (int)work[0].head.size() != np_) {
+      work.clear();
+      work.reserve(P);
+      for (int t = 0; t < P; ++t) work.emplace_back(np_, nb_, top_size);
+    }
     std::atomic<bool> ok(true);
+    const auto t2b = now();
+    std::vector<double> part_ms(P, 0.0);
     auto run = [&](int t) {
+      const auto r0 = now();
       Work& wt = work[t];
+      if (wt.touched_hi >= wt.touched_lo)
+        std::fill(wt.top.begin() + (valptr_[wt.touched_lo] - top0), wt.top.begin() + (valptr_[wt.touched_hi + 1] - top0), 0.0);
+      std::fill(wt.head.begin(), wt.head.end(), -1);
+      wt.touched_lo = np_; wt.touched_hi = -1;
+      for (int j = top_start_panel_ + t; j < np_; j += P) preparePanel(j, Cx);     // the top's panels: shared out
       for (int j = part_start_[t]; j < part_start_[t + 1]; ++j) {
         double* Pj = Lx_.data() + valptr_[j];
+        preparePanel(j, Cx);
         applyUpdates(j, Pj, wt);
         if (!factorPanel(Pj, dim_[j], m_[j])) { ok = false; return; }
         link(j, wt.head);
+        pushToTop(j, wt, top0);
       }
-      for (int j = top_start_; j < nb_; ++j)
-        if (wt.head[j] != -1) { applyUpdates(j, wt.top.data() + (valptr_[j] - top0), wt); wt.touched_lo = std::min(wt.touched_lo, j); wt.touched_hi = std::max(wt.touched_hi, j); }
+      part_ms[t] = ms(r0, now());
     };
     {
       std::vector<std::thread> th;
@@ -150,8 +168,8 @@ class BlockSparseCholesky {
     }
     if (!ok) return false;
     const auto t3 = now();
-    Work ws(nb_, (size_t)max_m_ * max_d_, 0);
-    for (int j = top_start_; j < nb_; ++j) {
+    Work ws(np_, nb_, 0);
+    for (int j = top_start_panel_; j < np_; ++j) {
       double* Pj = Lx_.data() + valptr_[j];
       const size_t len = (size_t)m_[j] * dim_[j];
       for (int t = 0; t < P; ++t) {
@@ -163,9 +181,14 @@ class BlockSparseCholesky {
       if (!factorPanel(Pj, dim_[j], m_[j])) return false;
       link(j, ws.head);
     }
+    if (timing) {
+      std::fprintf(stderr, "cholesky: set-up of the parts %.1f ms (top image %.1f MB per part); per part [ms]:", ms(t2, t2b), top_size * 8e-6);
+      for (int t = 0; t < P; ++t) std::fprintf(stderr, " %.0f", part_ms[t]);
+      std::fprintf(stderr, "\n");
+    }
     if (timing)
-      std::fprintf(stderr, "cholesky: symbolic %.1f ms, scatter %.1f ms, %d parts %.1f ms, top (%d blocks, %d columns) %.1f ms\n", ms(t0, t1),
-                   ms(t1, t2), P, ms(t2, t3), nb_ - top_start_, n_ - pbase_[top_start_], ms(t3, now()));
+      std::fprintf(stderr, "cholesky: %d blocks in %d panels, symbolic %.1f ms, value check %.1f ms, %d parts %.1f ms, top (%d panels, %d columns) %.1f ms\n", nb_, np_, ms(t0, t1),
+                   ms(t1, t2), P, ms(t2, t3), np_ - top_start_panel_, n_ - pbase_[top_start_panel_], ms(t3, now()));
     factored_ = true;
     return true;
   }
@@ -174,11 +197,12 @@ class BlockSparseCholesky {
   void solve(const double* b, double* x) const {
     if (!factored_) throw std::logic_error("solve before a successful factorize");
     std::vector<double> y(n_);
-    for (int j = 0; j < nb_; ++j) {
-      const double* s = b + obase_[perm_[j]];
-      for (int l = 0; l < dim_[j]; ++l) y[pbase_[j] + l] = s[l];
+    for (int J = 0; J < nb_; ++J) {
+      const double* s = b + obase_[J];
+      double* d = y.data() + ybase_[iperm_[J]];
+      for (int l = 0, dl = obase_[J + 1] - obase_[J]; l < dl; ++l) d[l] = s[l];
     }
-    const int split = part_start_.empty() ? nb_ : top_start_;      // row blocks >= split belong to the top
+    const int split = part_start_.empty() ? np_ : top_start_panel_;      // row blocks >= split belong to the top
     const int ysplit = pbase_[split];
     // L y' = y for block column j; rows in the top go to `top` (indexed from ysplit), which may be a private image
     auto forward = [&](int j, double* top) {
@@ -192,12 +216,12 @@ class BlockSparseCholesky {
         for (int r = c + 1; r < dj; ++r) yj[r] -= pc[r] * v;
       }
       // rows below the diagonal block, by runs of row blocks that are neighbours in the permuted order (contiguous in y)
-      for (long long q = colptr_[j] + 1; q < colptr_[j + 1];) {
-        const int ro = rowoff_[q], y0 = pbase_[rowblk_[q]];
-        const bool in_top = rowblk_[q] >= split;
-        int len = dim_[rowblk_[q]];
+      for (long long q = colptr_[j] + (panel_start_[j + 1] - panel_start_[j]); q < colptr_[j + 1];) {
+        const int ro = rowoff_[q], y0 = ybase_[rowblk_[q]];
+        const bool in_top = pos_panel_[rowblk_[q]] >= split;
+        int len = pdim_[rowblk_[q]];
         long long q2 = q + 1;
-        while (q2 < colptr_[j + 1] && pbase_[rowblk_[q2]] == y0 + len && (rowblk_[q2] >= split) == in_top) { len += dim_[rowblk_[q2]]; ++q2; }
+        while (q2 < colptr_[j + 1] && ybase_[rowblk_[q2]] == y0 + len && (pos_panel_[rowblk_[q2]] >= split) == in_top) { len += pdim_[rowblk_[q2]]; ++q2; }
         double* yr = in_top ? top + (y0 - ysplit) : y.data() + y0;
         for (int c = 0; c < dj; ++c) {
           const double* pc = P + ro + (size_t)c * mj;
@@ -211,11 +235,11 @@ class BlockSparseCholesky {
       const int dj = dim_[j], mj = m_[j];
       const double* P = Lx_.data() + valptr_[j];
       double* yj = y.data() + pbase_[j];
-      for (long long q = colptr_[j] + 1; q < colptr_[j + 1];) {
-        const int ro = rowoff_[q], y0 = pbase_[rowblk_[q]];
-        int len = dim_[rowblk_[q]];
+      for (long long q = colptr_[j] + (panel_start_[j + 1] - panel_start_[j]); q < colptr_[j + 1];) {
+        const int ro = rowoff_[q], y0 = ybase_[rowblk_[q]];
+        int len = pdim_[rowblk_[q]];
         long long q2 = q + 1;
-        while (q2 < colptr_[j + 1] && pbase_[rowblk_[q2]] == y0 + len) { len += dim_[rowblk_[q2]]; ++q2; }
+        while (q2 < colptr_[j + 1] && ybase_[rowblk_[q2]] == y0 + len) { len += pdim_[rowblk_[q2]]; ++q2; }
         const double* yr = y.data() + y0;
         for (int c = 0; c < dj; ++c) {
           const double* pc = P + ro + (size_t)c * mj;
@@ -233,8 +257,8 @@ class BlockSparseCholesky {
       }
     };
     if (part_start_.empty()) {
-      for (int j = 0; j < nb_; ++j) forward(j, y.data() + ysplit);
-      for (int j = nb_ - 1; j >= 0; --j) backward(j);
+      for (int j = 0; j < np_; ++j) forward(j, y.data() + ysplit);
+      for (int j = np_ - 1; j >= 0; --j) backward(j);
     } else {
       const int P = (int)part_start_.size() - 1;
       const size_t ntop = (size_t)(n_ - ysplit);
@@ -248,13 +272,14 @@ class BlockSparseCholesky {
       each_part([&](int t) { for (int j = part_start_[t]; j < part_start_[t + 1]; ++j) forward(j, tops[t].data()); });
       for (int t = 0; t < P; ++t)
         for (size_t i = 0; i < ntop; ++i) y[ysplit + i] += tops[t][i];
-      for (int j = top_start_; j < nb_; ++j) forward(j, y.data() + ysplit);
-      for (int j = nb_ - 1; j >= top_start_; --j) backward(j);
+      for (int j = top_start_panel_; j < np_; ++j) forward(j, y.data() + ysplit);
+      for (int j = np_ - 1; j >= top_start_panel_; --j) backward(j);
       each_part([&](int t) { for (int j = part_start_[t + 1] - 1; j >= part_start_[t]; --j) backward(j); });
     }
-    for (int j = 0; j < nb_; ++j) {
-      double* d = x + obase_[perm_[j]];
-      for (int l = 0; l < dim_[j]; ++l) d[l] = y[pbase_[j] + l];
+    for (int J = 0; J < nb_; ++J) {
+      const double* s = y.data() + ybase_[iperm_[J]];
+      double* d = x + obase_[J];
+      for (int l = 0, dl = obase_[J + 1] - obase_[J]; l < dl; ++l) d[l] = s[l];
     }
   }
 
@@ -294,57 +319,98 @@ class BlockSparseCholesky {
   // per-thread scratch of the numeric phase
   struct Work {
     std::vector<int> head, where;
-    std::vector<double> tmp, top;
+    std::vector<double> top;
     int touched_lo, touched_hi;
-    Work(int nb, size_t tmp_size, size_t top_size) : head(nb, -1), where(nb, 0), tmp(tmp_size), top(top_size, 0.0), touched_lo(nb), touched_hi(-1) {}
+    Work(int np, int nb, size_t top_size) : head(np, -1), where(nb, 0), top(top_size, 0.0), touched_lo(np), touched_hi(-1) {}
   };
-  // Left-looking step for block column j: P (the column's panel, or a private image of it) -= the products of the block
-  // columns queued in wk.head[j]; every one of them then moves on to the list of its next row block.
+  // Left-looking step for panel j: P (the panel, or a private image of it) -= the products of the panels queued in
+  // wk.head[j]; every one of them then moves on to the list of the panel of its next row block.  A queued panel k has
+  // rows in some of j's member blocks (usually all of them); each run of those that is contiguous in j's columns is one
+  // column tile of the update, applied to k's rows from that run downwards.
   void applyUpdates(int j, double* P, Work& wk) {
-    const int dj = dim_[j], mj = m_[j];
     for (long long p = colptr_[j]; p < colptr_[j + 1]; ++p) wk.where[rowblk_[p]] = rowoff_[p];
     for (int k = wk.head[j], knext; k != -1; k = knext) {
       knext = next_[k];
-      const long long p0 = pos_[k], pe = colptr_[k + 1];
-      const int dk = dim_[k], mk = m_[k], r0 = rowoff_[p0];
-      const double* T = Lx_.data() + valptr_[k] + r0;      // rows of block column k from block row j downwards
-      // P[rows of k below j, :] -= T * T[0:dj, :]^T, by runs of row blocks that are contiguous in both panels (in the
-      // banded part a descendant's rows map onto the target's rows as two or three runs: band, border)
-      for (long long q = p0; q < pe;) {
-        const int src = rowoff_[q] - r0, dst = wk.where[rowblk_[q]];
-        int len = dim_[rowblk_[q]];
-        long long q2 = q + 1;
-        while (q2 < pe && wk.where[rowblk_[q2]] == dst + len) { len += dim_[rowblk_[q2]]; ++q2; }
-        panelUpdate(T, mk, src, len, dk, dj, P + dst, mj, wk.tmp.data());
-        q = q2;
+      const long long pe = colptr_[k + 1];
+      const long long pj = updateFrom(k, pos_[k], j, P, wk.where.data());
+      pos_[k] = pj;
+      if (pj < pe) {
+        const int r = pos_panel_[rowblk_[pj]];
+        if (!(k < top_start_panel_ && r >= top_start_panel_)) { next_[k] = wk.head[r]; wk.head[r] = k; }   // a part's panel reaches the top by pushToTop
       }
-      pos_[k] = p0 + 1;
-      if (p0 + 1 < pe) { const int r = rowblk_[p0 + 1]; next_[k] = wk.head[r]; wk.head[r] = k; }
     }
     wk.head[j] = -1;
   }
-  // the finished block column j queues itself at its first row block below the diagonal
+  // P (panel j or an image of it; where[position] = row offset in it) -= the product of panel k's rows from row-list
+  // entry p0 on with its rows inside panel j, which start at p0.  Returns the entry of k's first row beyond panel j.
+  long long updateFrom(int k, long long p0, int j, double* P, const int* where) const {
+    const int mj = m_[j], dk = dim_[k], mk = m_[k];
+    const long long pe = colptr_[k + 1];
+    long long pj = p0;                                   // [p0, pj): k's rows inside panel j
+    while (pj < pe && pos_panel_[rowblk_[pj]] == j) ++pj;
+    for (long long qa = p0; qa < pj;) {
+      const int c0 = where[rowblk_[qa]];
+      int wd = pdim_[rowblk_[qa]];
+      long long qb = qa + 1;
+      while (qb < pj && where[rowblk_[qb]] == c0 + wd) { wd += pdim_[rowblk_[qb]]; ++qb; }
+      const int r0 = rowoff_[qa];
+      const double* T = Lx_.data() + valptr_[k] + r0;    // rows of panel k from this run downwards; its first wd rows are B
+      double* Pc = P + (size_t)c0 * mj;
+      // by runs of row blocks that are contiguous in both panels
+      for (long long q = qa; q < pe;) {
+        const int src = rowoff_[q] - r0, dst = where[rowblk_[q]];
+        int len = pdim_[rowblk_[q]];
+        long long q2 = q + 1;
+        while (q2 < pe && where[rowblk_[q2]] == dst + len) { len += pdim_[rowblk_[q2]]; ++q2; }
+        panelUpdate(T, mk, src, len, dk, wd, Pc + dst, mj);
+        q = q2;
+      }
+      qa = qb;
+    }
+    return pj;
+  }
+  // A part's finished panel k adds its products to the part's image of the top's panels right away, while it is in
+  // cache (left-looking, every top panel would stream the part's whole factor past it once more).
+  void pushToTop(int k, Work& wk, long long top0) {
+    const long long pe = colptr_[k + 1];
+    long long q = pe;
+    while (q > colptr_[k] && rowblk_[q - 1] >= top_start_) --q;      // rows are sorted: the top's are at the end
+    while (q < pe) {
+      const int j = pos_panel_[rowblk_[q]];
+      q = updateFrom(k, q, j, wk.top.data() + (valptr_[j] - top0), top_where_.data() + (size_t)(j - top_start_panel_) * (nb_ - top_start_) - top_start_);
+      wk.touched_lo = std::min(wk.touched_lo, j); wk.touched_hi = std::max(wk.touched_hi, j);
+    }
+  }
+  // the finished panel j queues itself at the panel of its first row block below the diagonal block
   void link(int j, std::vector<int>& head) {
-    if (colptr_[j + 1] - colptr_[j] > 1) {
-      pos_[j] = colptr_[j] + 1;
-      const int r = rowblk_[pos_[j]];
+    const long long q = colptr_[j] + (panel_start_[j + 1] - panel_start_[j]);
+    if (q < colptr_[j + 1]) {
+      pos_[j] = q;
+      const int r = pos_panel_[rowblk_[q]];
+      if (j < top_start_panel_ && r >= top_start_panel_) return;
       next_[j] = head[r]; head[r] = j;
     }
   }
 
-  // panel factorisation: Cholesky of the dj x dj diagonal block and the triangular solve of the rows below it
+  // panel factorisation: Cholesky of the dj x dj diagonal block and the triangular solve of the rows below it, by column
+  // tiles of 6: a tile first receives the products of the panel's earlier columns through the update kernel, then its
+  // own columns are finished one by one
   static bool factorPanel(double* P, int dj, int mj) {
-    for (int c = 0; c < dj; ++c) {
-      double* pc = P + (size_t)c * mj;
-      for (int k = 0; k < c; ++k) {
-        const double* pk = P + (size_t)k * mj;
-        const double b = pk[c];
-        for (int r = c; r < mj; ++r) pc[r] -= pk[r] * b;
+    for (int c0 = 0; c0 < dj; c0 += 6) {
+      const int c1 = std::min(dj, c0 + 6);
+      if (c0 > 0) panelUpdate(P + c0, mj, 0, mj - c0, c0, c1 - c0, P + c0 + (size_t)c0 * mj, mj);
+      for (int c = c0; c < c1; ++c) {
+        double* pc = P + (size_t)c * mj;
+        for (int k = c0; k < c; ++k) {
+          const double* pk = P + (size_t)k * mj;
+          const double b = pk[c];
+          for (int r = c; r < mj; ++r) pc[r] -= pk[r] * b;
+        }
+        const double d = pc[c];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        const double inv = 1.0 / std::sqrt(d);
+        for (int r = c; r < mj; ++r) pc[r] *= inv;
       }
-      const double d = pc[c];
-      if (!(d > 0.0) || !std::isfinite(d)) return false;
-      const double inv = 1.0 / std::sqrt(d);
-      for (int r = c; r < mj; ++r) pc[r] *= inv;
     }
     return true;
   }
@@ -384,9 +450,11 @@ class BlockSparseCholesky {
         cost[i] = w[order[i]] * m * m;
         total += cost[i];
       }
+      // every part but the first carries the rows of the separator on its left through all of its columns, which about
+      // doubles its work: the first part gets two shares
       double acc = 0;
       for (size_t i = 0; i < order.size(); ++i) {
-        stage[order[i]] = std::min(P - 1, (int)(acc / total * P));
+        stage[order[i]] = std::min(P - 1, std::max(0, (int)(acc / total * (P + 1)) - 1));
         acc += cost[i];
       }
       // The edges between two different parts have to lose an endpoint to the top.  Greedy vertex cover: the block with
@@ -434,9 +502,9 @@ class BlockSparseCholesky {
     const int P = (int)part_start_.size() - 1;
     for (int p2 = 0; p2 < P; ++p2)
       for (int j = part_start_[p2]; j < part_start_[p2 + 1]; ++j)
-        for (long long q = colptr_[j] + 1; q < colptr_[j + 1]; ++q) {
-          const int r = rowblk_[q];
-          if (r < top_start_ && r >= part_start_[p2 + 1]) { part_start_.clear(); top_start_ = 0; return; }
+        for (long long q = colptr_[j]; q < colptr_[j + 1]; ++q) {
+          const int r = pos_panel_[rowblk_[q]];
+          if (r < top_start_panel_ && r >= part_start_[p2 + 1]) { part_start_.clear(); top_start_ = 0; top_start_panel_ = 0; return; }
         }
     stats_.n_parts = P;
     stats_.n_top_blocks = nb_ - top_start_;
@@ -476,131 +544,171 @@ class BlockSparseCholesky {
       for (int I : kept_[J]) { adj[J].push_back(I); adj[I].push_back(J); }
     std::vector<int> w(nb_);
     for (int b = 0; b < nb_; ++b) w[b] = obase_[b + 1] - obase_[b];
+    work_.clear();
     partition(adj, w);         // fills perm_ / iperm_ (and the independent parts, if the blocks have coordinates)
     symbolic(adj, w);          // fills the panel layout
     checkParts();
-    amap_.assign(Cp_[n_], -1);
+    std::vector<int> amap(Cp_[n_], -1), apan(Cp_[n_], -1);   // value index -> entry of the panel `apan` (offset from its start)
     std::vector<char> keep(nb_, 0);
     for (int J = 0; J < nb_; ++J) {
       for (int I : kept_[J]) keep[I] = 1;
       keep[J] = 1;
-      const int pJ = iperm_[J];
-      int lastI = -1; long long base = 0; int ld = 0; bool transposed = false;
+      const int gJ = panel_of_[J], oJ = panel_off_[J], pJ = iperm_[J];
+      int lastI = -1, lastCol = -1; long long base = 0; int ld = 0, coff = 0; bool transposed = false;
       for (int c = obase_[J]; c < obase_[J + 1]; ++c) {
         const int lj = c - obase_[J];
         for (int k = Cp_[c]; k < Cp_[c + 1]; ++k) {
-          const int i = Ci_[k], I = blk_of_[i], li = i - obase_[I];
+          const int i = Ci_[k], I = blk_of_[i];
           if (!keep[I]) continue;
-          if (I == J) {                    // diagonal block: keep its lower triangle (r >= c)
-            amap_[k] = (int)(valptr_[pJ] + lj + (long long)li * m_[pJ]);
+          const int li = i - obase_[I];
+          if (panel_of_[I] == gJ) {        // inside the panel's diagonal block: its lower triangle
+            const int a = li + panel_off_[I], b = lj + oJ;
+            amap[k] = (int)(std::max(a, b) + (long long)std::min(a, b) * m_[gJ]);
+            apan[k] = gJ;
             continue;
           }
           if (I != lastI) {
             lastI = I;
             const int pI = iperm_[I];
-            const int col = std::min(pI, pJ), row = std::max(pI, pJ);
-            const int* rb = rowblk_.data() + colptr_[col];
-            const int* re = rowblk_.data() + colptr_[col + 1];
-            const int* it = std::lower_bound(rb, re, row);
-            if (it == re || *it != row) throw std::logic_error("symbolic factor misses an entry of the matrix");
-            ld = m_[col];
-            base = valptr_[col] + rowoff_[colptr_[col] + (it - rb)];
             transposed = (pI < pJ);        // entry (i, j) of the upper triangle sits at (row j, column i) of the lower factor
+            const int colBlock = transposed ? I : J, rowPos = transposed ? pJ : pI;
+            const int col = panel_of_[colBlock];
+            const long long first = colptr_[col] + (panel_start_[col + 1] - panel_start_[col]);
+            const int* rb = rowblk_.data() + first;
+            const int* re = rowblk_.data() + colptr_[col + 1];
+            const int* it = std::lower_bound(rb, re, rowPos);
+            if (it == re || *it != rowPos) throw std::logic_error("symbolic factor misses an entry of the matrix");
+            ld = m_[col];
+            coff = panel_off_[colBlock];
+            base = rowoff_[first + (it - rb)];
+            lastCol = col;
           }
-          amap_[k] = (int)(transposed ? base + lj + (long long)li * ld : base + li + (long long)lj * ld);
+          amap[k] = (int)(transposed ? base + lj + (long long)(li + coff) * ld : base + li + (long long)(lj + coff) * ld);
+          apan[k] = lastCol;
         }
       }
       for (int I : kept_[J]) keep[I] = 0;
       keep[J] = 0;
     }
+    // by destination panel (counting sort; sources stay in ascending order inside a panel), and the entries outside the
+    // kept blocks, whose values must be zero
+    sc_ptr_.assign(np_ + 1, 0);
+    size_t n_dropped = 0;
+    for (size_t k = 0; k < apan.size(); ++k) { if (apan[k] >= 0) ++sc_ptr_[apan[k] + 1]; else ++n_dropped; }
+    for (int g = 0; g < np_; ++g) sc_ptr_[g + 1] += sc_ptr_[g];
+    sc_src_.assign(sc_ptr_[np_], 0); sc_dst_.assign(sc_ptr_[np_], 0);
+    dropped_.clear(); dropped_.reserve(n_dropped);
+    {
+      std::vector<long long> fillp(sc_ptr_.begin(), sc_ptr_.end() - 1);
+      for (size_t k = 0; k < apan.size(); ++k) {
+        if (apan[k] < 0) { dropped_.push_back((int)k); continue; }
+        const long long e = fillp[apan[k]]++;
+        sc_src_[e] = (int)k; sc_dst_[e] = amap[k];
+      }
+    }
     symbolic_ = true;
     ++stats_.symbolic_passes;
   }
 
-  // values -> panels; false if a non-zero value falls outside the kept blocks
-  bool scatter(const double* Cx) {
-    const size_t nnz = amap_.size(), nl = Lx_.size();
-    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, nnz / 200000 + 1));   // small systems: not worth the threads
+  // false if a non-zero value falls outside the kept blocks
+  bool checkDropped(const double* Cx) const {
+    const size_t nd = dropped_.size();
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, nd / 200000 + 1));   // small systems: not worth the threads
     std::vector<char> inside(T, 1);
-    auto zero = [&](int t) { std::fill(Lx_.begin() + nl * t / T, Lx_.begin() + nl * (t + 1) / T, 0.0); };
-    auto fill = [&](int t) {
+    auto scan = [&](int t) {
       bool in = true;
-      for (size_t k = nnz * t / T, ke = nnz * (t + 1) / T; k < ke; ++k) {
-        const int a = amap_[k];
-        if (a >= 0) Lx_[a] = Cx[k];
-        else if (Cx[k] != 0.0) in = false;
-      }
+      for (size_t i = nd * t / T, ie = nd * (t + 1) / T; i < ie; ++i) if (Cx[dropped_[i]] != 0.0) in = false;
       inside[t] = in ? 1 : 0;
     };
-    auto each = [&](auto&& fn) {
-      std::vector<std::thread> th;
-      for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
-      fn(0);
-      for (std::thread& z : th) z.join();
-    };
-    each(zero);
-    each(fill);
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
+    scan(0);
+    for (std::thread& z : th) z.join();
     for (int t = 0; t < T; ++t) if (!inside[t]) return false;
     return true;
   }
+  // values -> panel g, right before the panel is worked on (it then sits in the cache of the thread that factorises it)
+  void preparePanel(int g, const double* Cx) {
+    double* P = Lx_.data() + valptr_[g];
+    std::fill(P, P + (valptr_[g + 1] - valptr_[g]), 0.0);
+    for (long long e = sc_ptr_[g]; e < sc_ptr_[g + 1]; ++e) P[sc_dst_[e]] = Cx[sc_src_[e]];
+  }
 
-  // P (len x DJ, leading dimension ldp) -= T[src : src + len, :] (len x DK, leading dimension ld) * T[0:DJ, :]^T.  This
-  // update is where the factorisation spends its flops; with the block dimensions known at compile time the DJ x DK
-  // coefficients and the DK values of a row stay in registers and the loop over the rows vectorises (DK loads, DJ
-  // load-subtract-stores per DK * DJ multiply-adds).
-  template <int DK, int DJ>
-  static void panelUpdateFixed(const double* __restrict__ T, int ld, int src, int len, double* __restrict__ P, int ldp) {
-    double B[DJ][DK];
-    for (int cj = 0; cj < DJ; ++cj)
-      for (int ck = 0; ck < DK; ++ck) B[cj][ck] = T[cj + (size_t)ck * ld];
+  // P (len x dj, leading dimension ldp) -= T[src : src + len, :] (len x dk, leading dimension ld) * T[0:dj, :]^T.  This
+  // update is where the factorisation spends its flops.  It runs in column tiles of DJ <= 6 and row tiles of 4 RV rows
+  // whose DJ x RV vector accumulators stay in registers over the whole dk loop: per column of T, RV row vectors and DJ
+  // broadcasts feed DJ RV fused multiply-adds, and P is read and written once.
+  enum { KC = 32 };   // columns of T per pass (the coefficient tile B lives on the stack)
+  template <int DJ, int RV>
+  static void updateTile(const double* __restrict__ T, int ld, int boff, int src, int len, int dk, double* __restrict__ P, int ldp) {
+    alignas(32) double B[KC][DJ];
+    for (int ck = 0; ck < dk; ++ck)
+      for (int cj = 0; cj < DJ; ++cj) B[ck][cj] = T[boff + cj + (size_t)ck * ld];
     const double* __restrict__ S = T + src;
-#pragma GCC ivdep
-    for (int r = 0; r < len; ++r) {
-      double a[DK];
-      for (int ck = 0; ck < DK; ++ck) a[ck] = S[r + (size_t)ck * ld];
-      for (int cj = 0; cj < DJ; ++cj) {
-        double s = a[0] * B[cj][0];
-        for (int ck = 1; ck < DK; ++ck) s += a[ck] * B[cj][ck];
-        P[r + (size_t)cj * ldp] -= s;
+    int r = 0;
+#if defined(__AVX2__) && defined(__FMA__)
+    for (; r + 4 * RV <= len; r += 4 * RV) {
+      __m256d acc[DJ][RV];
+#pragma GCC unroll 6
+      for (int cj = 0; cj < DJ; ++cj)
+#pragma GCC unroll 4
+        for (int v = 0; v < RV; ++v) acc[cj][v] = _mm256_loadu_pd(P + r + 4 * v + (size_t)cj * ldp);
+      for (int ck = 0; ck < dk; ++ck) {
+        __m256d a[RV];
+#pragma GCC unroll 4
+        for (int v = 0; v < RV; ++v) a[v] = _mm256_loadu_pd(S + r + 4 * v + (size_t)ck * ld);
+#pragma GCC unroll 6
+        for (int cj = 0; cj < DJ; ++cj) {
+          const __m256d bb = _mm256_broadcast_sd(&B[ck][cj]);
+#pragma GCC unroll 4
+          for (int v = 0; v < RV; ++v) acc[cj][v] = _mm256_fnmadd_pd(a[v], bb, acc[cj][v]);
+        }
       }
+#pragma GCC unroll 6
+      for (int cj = 0; cj < DJ; ++cj)
+#pragma GCC unroll 4
+        for (int v = 0; v < RV; ++v) _mm256_storeu_pd(P + r + 4 * v + (size_t)cj * ldp, acc[cj][v]);
+    }
+    for (; r + 4 <= len; r += 4) {
+      __m256d acc[DJ];
+#pragma GCC unroll 6
+      for (int cj = 0; cj < DJ; ++cj) acc[cj] = _mm256_loadu_pd(P + r + (size_t)cj * ldp);
+      for (int ck = 0; ck < dk; ++ck) {
+        const __m256d a0 = _mm256_loadu_pd(S + r + (size_t)ck * ld);
+#pragma GCC unroll 6
+        for (int cj = 0; cj < DJ; ++cj) acc[cj] = _mm256_fnmadd_pd(a0, _mm256_broadcast_sd(&B[ck][cj]), acc[cj]);
+      }
+#pragma GCC unroll 6
+      for (int cj = 0; cj < DJ; ++cj) _mm256_storeu_pd(P + r + (size_t)cj * ldp, acc[cj]);
+    }
+#endif
+    for (; r < len; ++r) {
+      double s[DJ];
+      for (int cj = 0; cj < DJ; ++cj) s[cj] = 0.0;
+      for (int ck = 0; ck < dk; ++ck) {
+        const double a = S[r + (size_t)ck * ld];
+        for (int cj = 0; cj < DJ; ++cj) s[cj] += a * B[ck][cj];
+      }
+      for (int cj = 0; cj < DJ; ++cj) P[r + (size_t)cj * ldp] -= s[cj];
     }
   }
-  template <int DK>
-  static bool panelUpdateDj(const double* T, int ld, int src, int len, int dj, double* P, int ldp) {
-    switch (dj) {
-      case 1: panelUpdateFixed<DK, 1>(T, ld, src, len, P, ldp); return true;
-      case 2: panelUpdateFixed<DK, 2>(T, ld, src, len, P, ldp); return true;
-      case 3: panelUpdateFixed<DK, 3>(T, ld, src, len, P, ldp); return true;
-      case 4: panelUpdateFixed<DK, 4>(T, ld, src, len, P, ldp); return true;
-      case 5: panelUpdateFixed<DK, 5>(T, ld, src, len, P, ldp); return true;
-      case 6: panelUpdateFixed<DK, 6>(T, ld, src, len, P, ldp); return true;
-      default: return false;
-    }
-  }
-  static void panelUpdate(const double* T, int ld, int src, int len, int dk, int dj, double* P, int ldp, double* tmp) {
-    bool done = false;
-    switch (dk) {
-      case 1: done = panelUpdateDj<1>(T, ld, src, len, dj, P, ldp); break;
-      case 2: done = panelUpdateDj<2>(T, ld, src, len, dj, P, ldp); break;
-      case 3: done = panelUpdateDj<3>(T, ld, src, len, dj, P, ldp); break;
-      case 4: done = panelUpdateDj<4>(T, ld, src, len, dj, P, ldp); break;
-      case 5: done = panelUpdateDj<5>(T, ld, src, len, dj, P, ldp); break;
-      case 6: done = panelUpdateDj<6>(T, ld, src, len, dj, P, ldp); break;
-      default: break;
-    }
-    if (done) return;
-    for (int cj = 0; cj < dj; ++cj) {     // any other block dimension: column by column through tmp
-      {
-        const double b = T[cj];
-        for (int r = 0; r < len; ++r) tmp[r] = T[src + r] * b;
+  static void panelUpdate(const double* T, int ld, int src, int len, int dk, int dj, double* P, int ldp) {
+    for (int k0 = 0; k0 < dk; k0 += KC) {
+      const double* Tk = T + (size_t)k0 * ld;
+      const int kc = std::min<int>(KC, dk - k0);
+      for (int j0 = 0; j0 < dj;) {
+        const int c = std::min(6, dj - j0);
+        double* Pj = P + (size_t)j0 * ldp;
+        switch (c) {
+          case 6: updateTile<6, 2>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+          case 5: updateTile<5, 2>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+          case 4: updateTile<4, 3>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+          case 3: updateTile<3, 3>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+          case 2: updateTile<2, 4>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+          default: updateTile<1, 4>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+        }
+        j0 += c;
       }
-      for (int ck = 1; ck < dk; ++ck) {
-        const double* a = T + (size_t)ck * ld;
-        const double b = a[cj];
-        for (int r = 0; r < len; ++r) tmp[r] += a[src + r] * b;
-      }
-      double* pd = P + (size_t)cj * ldp;
-      for (int r = 0; r < len; ++r) pd[r] -= tmp[r];
     }
   }
 
@@ -684,58 +792,154 @@ class BlockSparseCholesky {
     for (int i = 0; i < nb; ++i) iperm_[perm_[i]] = i;
   }
 
-  // Block structure of the factor in the new order and the panel layout.
-  void symbolic(const std::vector<std::vector<int>>& adj, const std::vector<int>& w) {
-    const int nb = nb_;
-    dim_.resize(nb); pbase_.resize(nb + 1);
-    pbase_[0] = 0;
-    for (int j = 0; j < nb; ++j) { dim_[j] = w[perm_[j]]; pbase_[j + 1] = pbase_[j] + dim_[j]; }
-    std::vector<std::vector<int>> st(nb), children(nb);
-    std::vector<int> mark(nb, -1);
-    for (int j = 0; j < nb; ++j) {
-      auto& s = st[j];
+  // Structure of the factor of a graph given, per node j in elimination order, by its neighbours > j (up[j]; duplicates
+  // allowed): st[j] = sorted rows below the diagonal of column j.
+  static void eliminationStructure(const std::vector<std::vector<int>>& up, std::vector<std::vector<int>>& st) {
+    const int nn = (int)up.size();
+    st.assign(nn, std::vector<int>());
+    std::vector<std::vector<int>> children(nn);
+    std::vector<int> mark(nn, -1);
+    for (int j = 0; j < nn; ++j) {
+      auto& sj = st[j];
       mark[j] = j;
-      for (int u : adj[perm_[j]]) { int i = iperm_[u]; if (i > j && mark[i] != j) { mark[i] = j; s.push_back(i); } }
-      for (int c : children[j]) {
-        for (int i : st[c]) if (mark[i] != j) { mark[i] = j; s.push_back(i); }
-      }
-      std::sort(s.begin(), s.end());
-      if (!s.empty()) children[s.front()].push_back(j);
+      for (int i : up[j]) if (mark[i] != j) { mark[i] = j; sj.push_back(i); }
+      for (int c : children[j])
+        for (int i : st[c]) if (mark[i] != j) { mark[i] = j; sj.push_back(i); }
+      std::sort(sj.begin(), sj.end());
+      if (!sj.empty()) children[sj.front()].push_back(j);
     }
-    colptr_.assign(nb + 1, 0); valptr_.assign(nb + 1, 0); m_.assign(nb, 0);
-    for (int j = 0; j < nb; ++j) colptr_[j + 1] = colptr_[j] + 1 + (long long)st[j].size();
-    rowblk_.resize(colptr_[nb]); rowoff_.resize(colptr_[nb]);
-    max_m_ = 0; max_d_ = 0;
-    stats_.flops = 0;
-    for (int j = 0; j < nb; ++j) {
-      long long p = colptr_[j];
-      int off = 0;
-      rowblk_[p] = j; rowoff_[p] = 0; off += dim_[j]; ++p;
-      for (int i : st[j]) { rowblk_[p] = i; rowoff_[p] = off; off += dim_[i]; ++p; }
-      m_[j] = off;
-      valptr_[j + 1] = valptr_[j] + (long long)off * dim_[j];
-      max_m_ = std::max(max_m_, off); max_d_ = std::max(max_d_, dim_[j]);
-      stats_.flops += (double)dim_[j] * off * off;      // ~ sum over the columns of (column count)^2
-      std::vector<int>().swap(st[j]);
-    }
-    if (valptr_[nb] > (long long)0x7fffffff) throw std::overflow_error("factor exceeds 2^31 entries");
-    Lx_.assign(valptr_[nb], 0.0);
-    stats_.n = n_; stats_.n_blocks = nb; stats_.nnz_factor = valptr_[nb];
   }
 
-  int n_ = 0, nb_ = 0, max_m_ = 0, max_d_ = 0;
+  // Block structure of the factor in the new order and the panel layout.  Neighbouring blocks of the order whose columns
+  // have the same structure below them (a pose coefficient and the bias coefficients whose support ends with it) share
+  // one panel: the updates then run on panels of up to MAX_PANEL columns instead of 3 or 6, which is what lets the
+  // update kernel reuse the rows it loads.
+  enum { MAX_PANEL = 24 };
+  void symbolic(const std::vector<std::vector<int>>& adj, const std::vector<int>& w) {
+    const int nb = nb_;
+    std::vector<std::vector<int>> up(nb), st;
+    for (int j = 0; j < nb; ++j)
+      for (int u : adj[perm_[j]]) if (iperm_[u] > j) up[j].push_back(iperm_[u]);
+    eliminationStructure(up, st);
+    // panels: maximal runs of positions j, j + 1, ... with struct(j) = {j + 1} + struct(j + 1), inside one part
+    std::vector<char> boundary(nb + 1, 0);
+    for (int b : part_start_) boundary[b] = 1;
+    boundary[top_start_] = 1;
+    panel_start_.assign(1, 0);
+    pos_panel_.assign(nb, 0);
+    double relax = 0.0;
+    {
+      // scalar rows below the diagonal block of every position
+      std::vector<long long> sz(nb, 0);
+      for (int j = 0; j < nb; ++j)
+        for (int i : st[j]) sz[j] += w[perm_[i]];
+      // tuning aids: MC_CHOLESKY_RELAX = share of explicit zeros a panel may hold (0: only blocks with identical
+      // structure share a panel), MC_CHOLESKY_MAX_PANEL = widest panel in columns (0: no panels)
+      relax = std::getenv("MC_CHOLESKY_RELAX") ? std::atof(std::getenv("MC_CHOLESKY_RELAX")) : 0.05;
+      const int maxp = std::getenv("MC_CHOLESKY_MAX_PANEL") ? std::atoi(std::getenv("MC_CHOLESKY_MAX_PANEL")) : MAX_PANEL;
+      const bool off = maxp <= 0;
+      int first = 0, width = w[perm_[0]];
+      for (int j = 1; j < nb; ++j) {
+        const int dj = w[perm_[j]];
+        bool same = !off && !boundary[j] && !st[j - 1].empty() && st[j - 1].front() == j && width + dj <= maxp;
+        if (same) {
+          // explicit zeros if [first, j] become one panel: member p gets the rows of j's structure it does not have itself
+          double zeros = 0, area = 0;
+          int after = dj;
+          for (int q = j - 1; q >= first; --q) {
+            const int dq = w[perm_[q]];
+            zeros += (double)std::max<long long>(0, sz[j] - (sz[q] - after)) * dq;
+            after += dq;
+          }
+          area = (double)(width + dj) * (sz[j] + width + dj);
+          same = zeros <= relax * area;
+        }
+        if (same) width += dj;
+        else { panel_start_.push_back(j); width = dj; first = j; }
+        pos_panel_[j] = (int)panel_start_.size() - 1;
+      }
+      panel_start_.push_back(nb);
+    }
+    const int np = np_ = (int)panel_start_.size() - 1;
+    // parts and top in panel numbers
+    for (int& b : part_start_) b = b < nb ? pos_panel_[b] : np;
+    top_start_panel_ = (!part_start_.empty() && top_start_ < nb) ? pos_panel_[top_start_] : (part_start_.empty() ? 0 : np);
+    dim_.assign(np, 0); pbase_.assign(np + 1, 0);
+    panel_of_.assign(nb, 0); panel_off_.assign(nb, 0); pdim_.assign(nb, 0); ybase_.assign(nb, 0);
+    for (int g = 0; g < np; ++g) {
+      for (int j = panel_start_[g]; j < panel_start_[g + 1]; ++j) {
+        panel_of_[perm_[j]] = g;
+        panel_off_[perm_[j]] = dim_[g];
+        pdim_[j] = w[perm_[j]];
+        ybase_[j] = pbase_[g] + dim_[g];
+        dim_[g] += pdim_[j];
+      }
+      pbase_[g + 1] = pbase_[g] + dim_[g];
+    }
+    // Members of a panel are eliminated together, so they must have one structure: every member gets the later members
+    // and the union of the members' neighbours beyond the panel (nothing new for members that had one structure already).
+    if (np < nb) {
+      std::vector<int> mark(nb, -1);
+      for (int g = 0; g < np; ++g) {
+        const int p0 = panel_start_[g], p1 = panel_start_[g + 1];
+        if (p1 - p0 < 2) continue;
+        std::vector<int> U;
+        for (int p = p0; p < p1; ++p)
+          for (int i : up[p]) if (i >= p1 && mark[i] != g) { mark[i] = g; U.push_back(i); }
+        for (int p = p0; p < p1; ++p) {
+          up[p] = U;
+          for (int q = p + 1; q < p1; ++q) up[p].push_back(q);
+        }
+      }
+      eliminationStructure(up, st);
+    }
+    std::vector<std::vector<int>>().swap(up);
+    // rows of a panel: its member blocks (the diagonal block), then the structure of its last member
+    colptr_.assign(np + 1, 0); valptr_.assign(np + 1, 0); m_.assign(np, 0);
+    for (int g = 0; g < np; ++g)
+      colptr_[g + 1] = colptr_[g] + (panel_start_[g + 1] - panel_start_[g]) + (long long)st[panel_start_[g + 1] - 1].size();
+    rowblk_.resize(colptr_[np]); rowoff_.resize(colptr_[np]);
+    max_m_ = 0; max_d_ = 0;
+    stats_.flops = 0;
+    for (int g = 0; g < np; ++g) {
+      long long p = colptr_[g];
+      int off = 0;
+      for (int j = panel_start_[g]; j < panel_start_[g + 1]; ++j) { rowblk_[p] = j; rowoff_[p] = off; off += pdim_[j]; ++p; }
+      for (int i : st[panel_start_[g + 1] - 1]) { rowblk_[p] = i; rowoff_[p] = off; off += pdim_[i]; ++p; }
+      m_[g] = off;
+      valptr_[g + 1] = valptr_[g] + (long long)off * dim_[g];
+      max_m_ = std::max(max_m_, off); max_d_ = std::max(max_d_, dim_[g]);
+      stats_.flops += (double)dim_[g] * off * off;      // ~ sum over the columns of (column count)^2
+    }
+    // row offsets of the top's blocks in every top panel (pushToTop)
+    top_where_.clear();
+    if (!part_start_.empty()) {
+      const int ntp = nb - top_start_;
+      top_where_.assign((size_t)(np - top_start_panel_) * ntp, -1);
+      for (int g = top_start_panel_; g < np; ++g)
+        for (long long q = colptr_[g]; q < colptr_[g + 1]; ++q) top_where_[(size_t)(g - top_start_panel_) * ntp + (rowblk_[q] - top_start_)] = rowoff_[q];
+    }
+    if (valptr_[np] > (long long)0x7fffffff) throw std::overflow_error("factor exceeds 2^31 entries");
+    Lx_.assign(valptr_[np], 0.0);
+    stats_.n = n_; stats_.n_blocks = nb; stats_.n_panels = np; stats_.nnz_factor = valptr_[np];
+  }
+
+  int n_ = 0, nb_ = 0, np_ = 0, max_m_ = 0, max_d_ = 0;      // scalar columns, blocks, panels
   bool analyzed_ = false, symbolic_ = false, factored_ = false;
   std::vector<int> Cp_, Ci_, blk_of_;
   std::vector<double> coord_;
   std::vector<int> next_;
   std::vector<long long> pos_;
-  int threads_ = 1, top_start_ = 0;
+  int threads_ = 1, top_start_ = 0, top_start_panel_ = 0;    // top_start_: position in perm_; part_start_ and top_start_panel_: panels
+  std::vector<int> panel_start_, pos_panel_, panel_of_, panel_off_, pdim_, ybase_, top_where_;   // panel -> first position; position -> panel; block -> panel, column offset inside it
   std::vector<int> part_start_;
   std::vector<std::vector<int>> kept_;
   std::vector<int> obase_, perm_, iperm_, dim_, pbase_, m_, rowblk_, rowoff_;
   std::vector<long long> colptr_, valptr_;
-  std::vector<int> amap_;   // value index -> panel entry (the panels hold fewer than 2^31 values, checked in symbolic)
+  std::vector<long long> sc_ptr_;           // per panel: its entries of the caller's value array ...
+  std::vector<int> sc_src_, sc_dst_, dropped_;   // ... (value index, offset in the panel); value indices outside the kept blocks
   std::vector<double> Lx_;
+  std::vector<Work> work_;
   Stats stats_;
 };
 

@@ -270,3 +270,20 @@ def test_numerically_zero_blocks_are_left_out_and_come_back(threads):
     # and back on the first matrix: blocks are never dropped again, the result is unchanged
     assert c.factorize(U.data) == 0
     assert np.abs(c.solve(b) - xr).max() <= 1e-9 * np.abs(xr).max()
+
+
+def test_linked_update_kernel_is_the_vector_one():
+    """The factorisation is header-only and two translation units instantiate it (mc_host.cpp with g++, mc_driver.hip
+    with hipcc); the linker keeps one copy.  That copy must be the AVX2 / FMA one: the one compiled without -march
+    gives the same results three times slower, which no other test notices."""
+    import shutil
+    import subprocess
+    from multical_amd import _lib
+    if not (shutil.which("nm") and shutil.which("objdump")):
+        pytest.skip("binutils not available")
+    lib = _lib.LIB_PATH
+    syms = [l.split()[-1] for l in subprocess.check_output(["nm", lib], text=True).splitlines()
+            if "BlockSparseCholesky10updateTileILi6ELi2" in l]
+    assert syms, "update kernel not found in " + lib
+    dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", "--disassemble=" + syms[0], lib], text=True)
+    assert "vfnmadd" in dis and "ymm" in dis
