@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstdint>
+#include <memory>
 #include <set>
 #include <stdexcept>
 #include <thread>
@@ -55,8 +56,9 @@ class BlockSparseCholesky {
   // on the blocks that hold a non-zero value there: the assembled pattern is the reference's, which includes the
   // structurally present but numerically zero blocks of padded spline coefficients (more than half of the entries on
   // the calibration problems), and a factor of the numerical pattern costs a fraction of one of the full pattern.  A
-  // block that becomes non-zero later (a time offset moved a live window over a knot) is added and the symbolic work
-  // redone; blocks are never dropped again.
+  // block that becomes non-zero later (a time offset moved a live window over a knot) usually lies inside the fill of the
+  // factor and has its place already; one that does not is added and the symbolic work redone.  Blocks are never dropped
+  // again.
   void analyze(int n, const int* Cp, const int* Ci, int n_blocks, const int* block_base) {
     n_ = n;
     std::vector<int> own_base;
@@ -105,7 +107,11 @@ class BlockSparseCholesky {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
-    if (!symbolic_) { markKept(Cx); buildSymbolic(); }
+    if (!symbolic_) {
+      markKept(Cx);
+      if (timing) std::fprintf(stderr, "cholesky: non-zero blocks marked in %.1f ms\n", ms(t0, now()));
+      buildSymbolic();
+    }
     const auto t1 = now();
     if (!checkDropped(Cx)) {     // a value outside the kept blocks: grow the structure
       markKept(Cx);
@@ -522,49 +528,63 @@ class BlockSparseCholesky {
     buildSymbolic();
   }
 
-  // Blocks with a non-zero value join the kept set (kept_[J] = row blocks I < J of block column J, unsorted).
-  void markKept(const double* Cx) {
-    std::vector<int> stamp(nb_, -1);
-    for (int J = 0; J < nb_; ++J) {
-      std::vector<int>& kj = kept_[J];
-      for (int I : kj) stamp[I] = J;
-      for (int c = obase_[J]; c < obase_[J + 1]; ++c)
-        for (int k = Cp_[c]; k < Cp_[c + 1]; ++k) {
-          if (Cx[k] == 0.0) continue;
-          const int I = blk_of_[Ci_[k]];
-          if (I != J && stamp[I] != J) { stamp[I] = J; kj.push_back(I); }
-        }
-    }
+  // fn(t, T) on T threads (T = threads_ when the work is worth it, else 1)
+  int threadsFor(size_t work) const { return (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, work / 200000 + 1)); }
+  template <class F> void eachThread(size_t work, F&& fn) const {
+    const int T = threadsFor(work);
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(fn, t, T);
+    fn(0, T);
+    for (std::thread& z : th) z.join();
+  }
+  // block columns [lo, hi) of thread t of T with about equal numbers of stored values
+  std::pair<int, int> blockRange(int t, int T) const {
+    auto cut = [&](int q) {
+      if (q <= 0) return 0;
+      if (q >= T) return nb_;
+      const long long target = (long long)Cp_[n_] * q / T;
+      const int c = (int)(std::lower_bound(Cp_.begin(), Cp_.end(), (int)target) - Cp_.begin());
+      return c >= n_ ? nb_ : blk_of_[c];
+    };
+    return {cut(t), cut(t + 1)};
   }
 
-  // Ordering, factor structure and the map from the caller's value array into the panels, for the kept blocks.
-  void buildSymbolic() {
-    std::vector<std::vector<int>> adj(nb_);
-    for (int J = 0; J < nb_; ++J)
-      for (int I : kept_[J]) { adj[J].push_back(I); adj[I].push_back(J); }
-    std::vector<int> w(nb_);
-    for (int b = 0; b < nb_; ++b) w[b] = obase_[b + 1] - obase_[b];
-    work_.clear();
-    partition(adj, w);         // fills perm_ / iperm_ (and the independent parts, if the blocks have coordinates)
-    symbolic(adj, w);          // fills the panel layout
-    checkParts();
-    std::vector<int> amap(Cp_[n_], -1), apan(Cp_[n_], -1);   // value index -> entry of the panel `apan` (offset from its start)
+  // Blocks with a non-zero value join the kept set (kept_[J] = row blocks I < J of block column J, unsorted).
+  void markKept(const double* Cx) {
+    eachThread((size_t)Cp_[n_], [&](int t, int T) {
+      std::vector<int> stamp(nb_, -1);
+      const std::pair<int, int> range = blockRange(t, T);
+      for (int J = range.first; J < range.second; ++J) {
+        std::vector<int>& kj = kept_[J];
+        for (int I : kj) stamp[I] = J;
+        for (int c = obase_[J]; c < obase_[J + 1]; ++c)
+          for (int k = Cp_[c]; k < Cp_[c + 1]; ++k) {
+            if (Cx[k] == 0.0) continue;
+            const int I = blk_of_[Ci_[k]];
+            if (I != J && stamp[I] != J) { stamp[I] = J; kj.push_back(I); }
+          }
+      }
+    });
+  }
+
+  // emit(value index, panel, offset in the panel) for every stored value of block columns [Jlo, Jhi); panel = -1 for a value
+  // without a place in the factor.  false if a kept block has no place (the symbolic structure would be wrong).
+  template <class E> bool mapBlockColumns(int Jlo, int Jhi, E&& emit) const {
+    bool ok = true;
     std::vector<char> keep(nb_, 0);
-    for (int J = 0; J < nb_; ++J) {
+    for (int J = Jlo; J < Jhi; ++J) {
       for (int I : kept_[J]) keep[I] = 1;
       keep[J] = 1;
       const int gJ = panel_of_[J], oJ = panel_off_[J], pJ = iperm_[J];
-      int lastI = -1, lastCol = -1; long long base = 0; int ld = 0, coff = 0; bool transposed = false;
+      int lastI = -1, lastCol = -1; long long base = 0; int ld = 0, coff = 0; bool transposed = false, found = false;
       for (int c = obase_[J]; c < obase_[J + 1]; ++c) {
         const int lj = c - obase_[J];
         for (int k = Cp_[c]; k < Cp_[c + 1]; ++k) {
           const int i = Ci_[k], I = blk_of_[i];
-          if (!keep[I]) continue;
           const int li = i - obase_[I];
           if (panel_of_[I] == gJ) {        // inside the panel's diagonal block: its lower triangle
             const int a = li + panel_off_[I], b = lj + oJ;
-            amap[k] = (int)(std::max(a, b) + (long long)std::min(a, b) * m_[gJ]);
-            apan[k] = gJ;
+            emit(k, gJ, (int)(std::max(a, b) + (long long)std::min(a, b) * m_[gJ]));
             continue;
           }
           if (I != lastI) {
@@ -577,42 +597,85 @@ class BlockSparseCholesky {
             const int* rb = rowblk_.data() + first;
             const int* re = rowblk_.data() + colptr_[col + 1];
             const int* it = std::lower_bound(rb, re, rowPos);
-            if (it == re || *it != rowPos) throw std::logic_error("symbolic factor misses an entry of the matrix");
-            ld = m_[col];
-            coff = panel_off_[colBlock];
-            base = rowoff_[first + (it - rb)];
-            lastCol = col;
+            // A block of the assembled pattern that holds only zeros now, but whose place exists in the factor anyway (it
+            // lies inside the fill), is mapped too: if it becomes non-zero later -- a time offset moved a live window over
+            // a knot -- nothing has to be redone.  Only zero blocks outside the factor's structure are left out.
+            found = it != re && *it == rowPos;
+            if (found) {
+              ld = m_[col];
+              coff = panel_off_[colBlock];
+              base = rowoff_[first + (it - rb)];
+              lastCol = col;
+            } else if (keep[I]) {
+              ok = false;
+            }
           }
-          amap[k] = (int)(transposed ? base + lj + (long long)(li + coff) * ld : base + li + (long long)(lj + coff) * ld);
-          apan[k] = lastCol;
+          if (!found) { emit(k, -1, 0); continue; }
+          emit(k, lastCol, (int)(transposed ? base + lj + (long long)(li + coff) * ld : base + li + (long long)(lj + coff) * ld));
         }
       }
       for (int I : kept_[J]) keep[I] = 0;
       keep[J] = 0;
     }
-    // by destination panel (counting sort; sources stay in ascending order inside a panel), and the entries outside the
-    // kept blocks, whose values must be zero
+    return ok;
+  }
+
+  // Ordering, factor structure and the map from the caller's value array into the panels, for the kept blocks.
+  void buildSymbolic() {
+    std::vector<std::vector<int>> adj(nb_);
+    for (int J = 0; J < nb_; ++J)
+      for (int I : kept_[J]) { adj[J].push_back(I); adj[I].push_back(J); }
+    std::vector<int> w(nb_);
+    for (int b = 0; b < nb_; ++b) w[b] = obase_[b + 1] - obase_[b];
+    work_.clear();
+    const bool timing = std::getenv("MC_CHOLESKY_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto s0 = now();
+    partition(adj, w);         // fills perm_ / iperm_ (and the independent parts, if the blocks have coordinates)
+    const auto s1 = now();
+    symbolic(adj, w);          // fills the panel layout
+    checkParts();
+    const auto s2 = now();
+    // Value map: every stored value goes to an entry of a panel (sc_src_ -> sc_dst_, grouped by panel, ascending value
+    // index inside a panel) or, a zero block outside the factor's structure, to dropped_.  Two passes over the pattern on
+    // all threads, count then write; the arrays are first touched by the threads that fill them.
+    const int T = threadsFor((size_t)Cp_[n_]);
+    std::vector<std::vector<long long>> cnt(T, std::vector<long long>(np_ + 1, 0));   // per thread: entries per panel, dropped at [np_]
+    std::atomic<bool> missing(false);
+    eachThread((size_t)Cp_[n_], [&](int t, int) {
+      std::vector<long long>& c = cnt[t];
+      const std::pair<int, int> range = blockRange(t, T);
+      if (!mapBlockColumns(range.first, range.second, [&](int, int panel, int) { ++c[panel >= 0 ? panel : np_]; })) missing = true;
+    });
+    if (missing) throw std::logic_error("symbolic factor misses an entry of the matrix");
     sc_ptr_.assign(np_ + 1, 0);
-    size_t n_dropped = 0;
-    for (size_t k = 0; k < apan.size(); ++k) { if (apan[k] >= 0) ++sc_ptr_[apan[k] + 1]; else ++n_dropped; }
-    for (int g = 0; g < np_; ++g) sc_ptr_[g + 1] += sc_ptr_[g];
-    sc_src_.assign(sc_ptr_[np_], 0); sc_dst_.assign(sc_ptr_[np_], 0);
-    dropped_.clear(); dropped_.reserve(n_dropped);
-    {
-      std::vector<long long> fillp(sc_ptr_.begin(), sc_ptr_.end() - 1);
-      for (size_t k = 0; k < apan.size(); ++k) {
-        if (apan[k] < 0) { dropped_.push_back((int)k); continue; }
-        const long long e = fillp[apan[k]]++;
-        sc_src_[e] = (int)k; sc_dst_[e] = amap[k];
-      }
+    long long run = 0, drop = 0;
+    for (int g = 0; g < np_; ++g) {
+      sc_ptr_[g] = run;
+      for (int t = 0; t < T; ++t) { const long long c = cnt[t][g]; cnt[t][g] = run; run += c; }
     }
+    sc_ptr_[np_] = run;
+    for (int t = 0; t < T; ++t) { const long long c = cnt[t][np_]; cnt[t][np_] = drop; drop += c; }
+    sc_src_.reset(new int[run]); sc_dst_.reset(new int[run]);
+    dropped_.reset(new int[drop]); n_dropped_ = (size_t)drop;
+    eachThread((size_t)Cp_[n_], [&](int t, int) {
+      std::vector<long long>& at = cnt[t];
+      const std::pair<int, int> range = blockRange(t, T);
+      mapBlockColumns(range.first, range.second, [&](int k, int panel, int offset) {
+        if (panel < 0) { dropped_[at[np_]++] = k; return; }
+        const long long e = at[panel]++;
+        sc_src_[e] = k; sc_dst_[e] = offset;
+      });
+    });
+    if (timing) std::fprintf(stderr, "cholesky: symbolic phase: ordering %.1f ms, structure %.1f ms, value map %.1f ms\n", ms(s0, s1), ms(s1, s2), ms(s2, now()));
     symbolic_ = true;
     ++stats_.symbolic_passes;
   }
 
   // false if a non-zero value falls outside the kept blocks
   bool checkDropped(const double* Cx) const {
-    const size_t nd = dropped_.size();
+    const size_t nd = n_dropped_;
     const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads_, nd / 200000 + 1));   // small systems: not worth the threads
     std::vector<char> inside(T, 1);
     auto scan = [&](int t) {
@@ -937,7 +1000,8 @@ class BlockSparseCholesky {
   std::vector<int> obase_, perm_, iperm_, dim_, pbase_, m_, rowblk_, rowoff_;
   std::vector<long long> colptr_, valptr_;
   std::vector<long long> sc_ptr_;           // per panel: its entries of the caller's value array ...
-  std::vector<int> sc_src_, sc_dst_, dropped_;   // ... (value index, offset in the panel); value indices outside the kept blocks
+  std::unique_ptr<int[]> sc_src_, sc_dst_, dropped_;   // ... (value index, offset in the panel); value indices outside the kept blocks
+  size_t n_dropped_ = 0;
   std::vector<double> Lx_;
   std::vector<Work> work_;
   Stats stats_;

@@ -287,3 +287,31 @@ def test_linked_update_kernel_is_the_vector_one():
     assert syms, "update kernel not found in " + lib
     dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", "--disassemble=" + syms[0], lib], text=True)
     assert "vfnmadd" in dis and "ymm" in dis
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_zero_block_inside_the_fill_needs_no_new_structure(threads):
+    """A stored-but-zero block whose place exists in the factor anyway (it lies inside the fill) is mapped from the start:
+    when it becomes non-zero the factor structure stays as it is and the answer is right."""
+    rng = np.random.default_rng(41)
+    n_band = 500
+    U, base, H = arrowhead_problem(rng, n_band=n_band, extra_pairs=300)
+    cols = np.repeat(np.arange(U.shape[0]), np.diff(U.indptr))
+    near = np.nonzero((U.data == 0.0) & (cols > U.indices) & (cols - U.indices <= 40))[0]
+    b = rng.standard_normal(U.shape[0])
+    absorbed = 0
+    for k in near[:: max(1, near.size // 10)]:
+        c = Chol()
+        c.analyze(U, base)
+        assert c.lib.mc_cholesky_set_block_coordinates(c.h, _dp(_coords(base, n_band)), threads) == 0
+        assert c.factorize(U.data) == 0
+        nnz0 = c.stats()[1]
+        i, j = U.indices[k], cols[k]
+        H3 = H.copy()
+        H3[i, j] = H3[j, i] = 0.25
+        H3[i, i] += 1.0; H3[j, j] += 1.0
+        assert c.factorize(H3[U.indices, cols]) == 0
+        x3 = np.linalg.solve(H3, b)
+        assert np.abs(c.solve(b) - x3).max() <= 1e-9 * np.abs(x3).max()
+        absorbed += c.stats()[1] == nnz0
+    assert absorbed > 0
