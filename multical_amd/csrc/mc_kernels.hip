@@ -175,6 +175,9 @@ __device__ __forceinline__ void f1_live(int p, int ncoef, int rc0, int coef_shif
 __device__ __forceinline__ void f1_flush(const FpView& f, const DevCommon& dc, const double* Msh, const double* w, int rc0,
                                          int coef_shift, const int* glc, const int* gk, const int* ggc, int n_nb, int nglob,
                                          bool board_part, int tid, int nthr = 256) {
+#ifdef MC_F1_NOFLUSH
+  if (dc.useM >= 0) return;   // experiment: what the kernel costs without the expansion of M to Hessian entries
+#endif
   const int ncoef = rc0 >= 0 ? 36 : 0;
   const int nlive = ncoef + nglob, M = ncoef + n_nb;
   const int npair = board_part ? (nlive - M) * nlive : M * (M + 1) / 2;
@@ -449,6 +452,216 @@ __global__ __launch_bounds__(256, MC_RB_OCC) void k_reproj_build(const ReprojBat
   MC_MARK(2);   // waiting for the other waves
   f1_flush(f, dc, Mimg, cml.w, last_info[1], last_info[2], gl_all[lw][0], gl_all[lw][1], gl_all[lw][2], last_info[3], last_info[3], false, tid, 256);
   MC_MARK(6);   // image flush
+}
+
+// buildSystem for F1, second shape: the CORNERS of an image are shared out, not its observations.  An aprilgrid
+// observation has up to 144 corners, i.e. 2 - 3 passes of 64 lanes with the last one nearly empty, and an image has 1 - 6
+// observations for 4 waves: with a wave per observation the critical path was 3 passes plus a chain of dependent loads
+// (group -> footprint -> record) per observation.  Here
+//   1. all 256 threads stage the records and chain matrices of the image's observations at once (rounds of OB);
+//   2. the corners of all observations form one list; a wave takes 64 consecutive ones per pass (lane -> observation by
+//      the prefix table, its record read from LDS per lane) and reduces the 7 x 7 Gram of every observation present in the
+//      pass on the fp64 matrix cores, rows of other observations masked to zero, into the observation's G in LDS;
+//   3. after one barrier a wave per observation forms M = Kt^T G Kt, adds the image-level part to Mimg and flushes the
+//      board rows / columns, exactly as k_reproj_build does;
+//   4. image-level flush by the whole workgroup.
+#ifndef MC_F1_OB
+#define MC_F1_OB 4
+#endif
+// 39.3 KB of LDS: four workgroups per CU where the registers allow it (109 VGPRs without atan / exp)
+template <bool EQUI, bool EXPW>
+__global__ __launch_bounds__(256, (EQUI || EXPW) ? MC_RB_OCC : 4) void k_reproj_build_img(const ReprojBatchView* __restrict__ views, DevCommon dc,
+                                                         const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
+                                                         const F1Common* __restrict__ common, const F1Chain* __restrict__ chain,
+                                                         int jpart_base) {
+  enum { ZW = 2 * 64 + 4, FPW = 512, O_T = 0, O_M = 140, O_FP = 352,   // phase 3 reuses the wave's z tile: T, M, the staged footprint
+         OB = MC_F1_OB };
+  constexpr int NCM = (int)(sizeof(F1Common) / 8), NCK = 6 * F1_CORE;
+  static_assert(O_M + 210 <= O_FP && O_FP + FPW / 2 <= 7 * ZW, "wave tile layout");
+  __shared__ double zs_all[4][7 * ZW];
+  __shared__ double cm_s[OB][NCM];
+  __shared__ double K_s[OB][NCK];
+  __shared__ double Gs[OB][49];
+  __shared__ int gl_all[4][3][13];
+  __shared__ double Mimg[210];
+  __shared__ double red[4];
+  __shared__ int last_info[7];
+  __shared__ int pre[OB + 1], gfirst[OB], gcount[OB], gfp[OB], ook[OB];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  double* zs = zs_all[wv];
+  int* fpl = reinterpret_cast<int*>(zs + O_FP);
+  int* glc = gl_all[wv][0]; int* gk = gl_all[wv][1]; int* ggc = gl_all[wv][2];
+  const ImageRec im = images[blockIdx.x];
+  const ReprojBatchView b = views[groups[im.first].batch];   // an image is one camera's: one batch
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  for (int i = tid; i < 210; i += 256) Mimg[i] = 0.0;
+  if (tid < 7) last_info[tid] = 0;
+  double Jacc = 0.0;
+  const int c16 = lane & 15, kr = lane >> 4;
+  for (int ob0 = 0; ob0 < im.count; ob0 += OB) {
+    const int nob = min((int)OB, im.count - ob0);
+    __syncthreads();   // Mimg zeroed / the previous round is done with the staged records
+    // ---- 1. records, chain matrices, group descriptors
+    for (int i = tid; i < nob * NCM; i += 256) {
+      const int o = i / NCM, j = i - o * NCM;
+      cm_s[o][j] = reinterpret_cast<const double*>(common + im.first + ob0 + o)[j];
+    }
+    for (int i = tid; i < nob * NCK; i += 256) {
+      const int o = i / NCK, j = i - o * NCK;
+      K_s[o][j] = chain[im.first + ob0 + o].K[j];
+    }
+    for (int i = tid; i < nob * 49; i += 256) (&Gs[0][0])[i] = 0.0;
+    if (tid < nob) {
+      const GroupRec gr = groups[im.first + ob0 + tid];
+      gfirst[tid] = gr.term_first; gcount[tid] = gr.term_count; gfp[tid] = gr.fp;
+    }
+    __syncthreads();
+    if (tid < nob) {
+      const F1Common& cmo = *reinterpret_cast<const F1Common*>(cm_s[tid]);
+      int ok = 1;
+      if (!cmo.ok) { atomicOr(dc.status, STATUS_TIME_OUT_OF_SPLINE); ok = 0; }
+      else {
+        // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
+        const FpView f = fp_view_at(dc.fp_data + dc.fp_off[gfp[tid]]);
+        const int shift = cmo.seg - f.coef_lo;
+        if (f.rolecol[F1_ROLE_COEF] >= 0 && (shift < 0 || shift + S6 > f.nbuf)) { atomicOr(dc.status, STATUS_BUFFER_EXCEEDED); ok = 0; }
+      }
+      ook[tid] = ok;
+    }
+    wave_sync();   // the lanes above are all in wave 0
+    if (tid == 0) {
+      int run = 0;
+      for (int o = 0; o < nob; ++o) { pre[o] = run; run += ook[o] ? gcount[o] : 0; }
+      pre[nob] = run;
+    }
+    __syncthreads();
+    // ---- 2. corner passes
+    const int ctot = pre[nob];
+    for (int base = 64 * wv; base < ctot; base += 256) {
+      const int c = base + lane;
+      const int nrows = 2 * min(64, ctot - base);
+      if (c < ctot) {
+        int o = 0;
+        while (o + 1 < nob && c >= pre[o + 1]) ++o;
+        const int term = gfirst[o] + (c - pre[o]);
+        const F1Common& cmo = *reinterpret_cast<const F1Common*>(cm_s[o]);
+        double pc[3], Jc[6], e[2], sw;
+        TermOut out;
+        f1_project<EQUI, EXPW>(b, dc.x, cmo, term, dc.useM != 0, true, pc, Jc, e, sw, out);
+        Jacc += out.w * out.chi2;
+        dc.chi2[b.term_base_global + term] = out.chi2;
+        if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
+        const double a0[3] = {-sw * Jc[0], -sw * Jc[1], -sw * Jc[2]}, a1[3] = {-sw * Jc[3], -sw * Jc[4], -sw * Jc[5]};
+        double c0[3], c1[3];
+        v3_cross(a0, pc, c0);
+        v3_cross(a1, pc, c1);
+        double2* zp = reinterpret_cast<double2*>(zs + 2 * lane);
+        constexpr int Z2 = ZW / 2;
+        zp[0 * Z2] = make_double2(a0[0], a1[0]); zp[1 * Z2] = make_double2(a0[1], a1[1]); zp[2 * Z2] = make_double2(a0[2], a1[2]);
+        zp[3 * Z2] = make_double2(c0[0], c1[0]); zp[4 * Z2] = make_double2(c0[1], c1[1]); zp[5 * Z2] = make_double2(c0[2], c1[2]);
+        zp[6 * Z2] = make_double2(e[0], e[1]);
+      }
+      wave_sync();
+      // 7 x 7 Gram per observation present in the pass (rows [ra, rb) of the tile), see k_reproj_build for the operand layout
+      int o_lo = 0;
+      while (o_lo + 1 < nob && base >= pre[o_lo + 1]) ++o_lo;
+      for (int oo = o_lo; oo < nob && pre[oo] < base + 64; ++oo) {
+        const int ra = 2 * max(pre[oo] - base, 0), rb = min(2 * (pre[oo + 1] - base), nrows);
+        if (rb <= ra) continue;
+        f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int st = ra >> 2; 4 * st < rb; st += 2) {
+          const int r0 = 4 * st + kr, r1 = r0 + 4;
+          const double v0 = (c16 < 7 && r0 >= ra && r0 < rb) ? zs[c16 * ZW + r0] : 0.0;
+          const double v1 = (c16 < 7 && r1 >= ra && r1 < rb) ? zs[c16 * ZW + r1] : 0.0;
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
+        }
+        // C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
+        if (c16 < 7) {
+          atomicAdd(&Gs[oo][kr * 7 + c16], acc0[0] + acc1[0]);
+          if (kr + 4 < 7) atomicAdd(&Gs[oo][(kr + 4) * 7 + c16], acc0[1] + acc1[1]);
+        }
+      }
+      wave_sync();   // the next pass overwrites the tile
+    }
+    __syncthreads();   // every observation's G is complete
+    // ---- 3. a wave per observation: G -> T = G Kt -> M = Kt^T T (Kt = [K 0; 0 1]), image part to Mimg, board part flushed
+    for (int o = wv; o < nob; o += 4) {
+      if (!ook[o]) continue;
+      const int fp_begin = dc.fp_off[gfp[o]], fp_len = dc.fp_off[gfp[o] + 1] - fp_begin;
+      const bool fp_staged = fp_len <= FPW;
+      if (fp_staged) for (int i = lane; i < fp_len; i += 64) fpl[i] = dc.fp_data[fp_begin + i];
+      wave_sync();
+      const F1Common& cm = *reinterpret_cast<const F1Common*>(cm_s[o]);
+      const double* Ks = K_s[o];
+      const double* G = Gs[o];
+      FpView f = fp_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + fp_begin);
+      const int rc0 = f.rolecol[F1_ROLE_COEF];
+      const int coef_shift = rc0 >= 0 ? cm.seg - f.coef_lo : 0;
+      const int a_qcb = f.rolecol[F1_ROLE_QCB] >= 0, a_tcb = f.rolecol[F1_ROLE_TCB] >= 0, a_toff = f.rolecol[F1_ROLE_TOFF] >= 0;
+      const int a_qpw = f.rolecol[F1_ROLE_QPW] >= 0, a_tpw = f.rolecol[F1_ROLE_TPW] >= 0;
+      const int n_nb = 3 * a_qcb + 3 * a_tcb + a_toff;
+      const int n_glob = n_nb + 3 * a_qpw + 3 * a_tpw;
+      if (lane < 13) {
+        int role, d, pos, kcore;
+        if (lane < 3) { role = F1_ROLE_QCB; d = lane; pos = 0; kcore = 6 + d; }
+        else if (lane < 6) { role = F1_ROLE_TCB; d = lane - 3; pos = 3 * a_qcb; kcore = 9 + d; }
+        else if (lane == 6) { role = F1_ROLE_TOFF; d = 0; pos = 3 * a_qcb + 3 * a_tcb; kcore = 18; }
+        else if (lane < 10) { role = F1_ROLE_QPW; d = lane - 7; pos = n_nb; kcore = 12 + d; }
+        else { role = F1_ROLE_TPW; d = lane - 10; pos = n_nb + 3 * a_qpw; kcore = 15 + d; }
+        const int rc = f.rolecol[role];
+        if (rc >= 0) {
+          glc[pos + d] = rc + d; gk[pos + d] = kcore;
+          const int g = dc.rep ? dc.gcb[f.blocks[4 * f.colblk[rc]]] : -1;
+          ggc[pos + d] = g >= 0 ? g + d : -1;
+        }
+      }
+      for (int idx = lane; idx < 140; idx += 64) {
+        const int i = idx / 20, c = idx - 20 * i;
+        double t = G[i * 7 + 6];
+        if (c < F1_CORE) {
+          t = 0.0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) t += G[i * 7 + j] * Ks[j * F1_CORE + c];
+        }
+        zs[O_T + idx] = t;
+      }
+      wave_sync();
+      for (int idx = lane; idx < 210; idx += 64) {
+        int bb = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+        while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
+        while (bb * (bb + 1) / 2 > idx) --bb;
+        const int ea = idx - bb * (bb + 1) / 2, eb = bb;
+        double m = zs[O_T + 6 * 20 + eb];
+        if (ea < F1_CORE) {
+          m = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) m += Ks[i * F1_CORE + ea] * zs[O_T + i * 20 + eb];
+        }
+        zs[O_M + idx] = m;
+        const bool board_entry = (ea >= 12 && ea <= 17) || (eb >= 12 && eb <= 17);
+        if (!board_entry) atomicAdd(&Mimg[idx], m);
+      }
+      wave_sync();
+      f1_flush(f, dc, zs + O_M, cm.w, rc0, coef_shift, glc, gk, ggc, n_nb, n_glob, true, lane, 64);
+      if (ob0 + o == im.count - 1 && lane == 0) {
+        last_info[0] = 1; last_info[1] = rc0; last_info[2] = coef_shift; last_info[3] = n_nb; last_info[4] = fp_staged ? 1 : 0;
+        last_info[5] = fp_begin; last_info[6] = o;
+      }
+      wave_sync();   // the flush is done with the tile and the tables before the wave's next observation
+    }
+  }
+  Jacc = wave_sum(Jacc);
+  if (lane == 0) red[wv] = Jacc;
+  __syncthreads();
+  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (!last_info[0]) return;
+  // image-level part through the last observation's tables, which its wave left in place (same camera, same time: same
+  // coefficient buffer, extrinsics and time-offset blocks)
+  const int lo = last_info[6], lw = lo & 3;
+  FpView f = last_info[4] ? fp_view_at(reinterpret_cast<const int*>(zs_all[lw] + O_FP)) : fp_view_at(dc.fp_data + last_info[5]);
+  const F1Common& cml = *reinterpret_cast<const F1Common*>(cm_s[lo]);
+  f1_flush(f, dc, Mimg, cml.w, last_info[1], last_info[2], gl_all[lw][0], gl_all[lw][1], gl_all[lw][2], last_info[3], last_info[3], false, tid, 256);
 }
 
 __device__ __forceinline__ int b_pose_first_block(const LidarBatchView& b) { return b.sp.first_block; }
@@ -1968,8 +2181,12 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
         hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
                            build ? L.chain.p : nullptr);
         if (build) {
-          auto kb = L.reproj_equi ? (L.reproj_expw ? k_reproj_build<true, true> : k_reproj_build<true, false>)
-                                  : (L.reproj_expw ? k_reproj_build<false, true> : k_reproj_build<false, false>);
+          // MC_F1_WAVE_PER_OBSERVATION=1: the first shape of the kernel (kept for comparison)
+          static const bool per_obs = std::getenv("MC_F1_WAVE_PER_OBSERVATION") != nullptr;
+          auto kb = per_obs ? (L.reproj_equi ? (L.reproj_expw ? k_reproj_build<true, true> : k_reproj_build<true, false>)
+                                             : (L.reproj_expw ? k_reproj_build<false, true> : k_reproj_build<false, false>))
+                            : (L.reproj_equi ? (L.reproj_expw ? k_reproj_build_img<true, true> : k_reproj_build_img<true, false>)
+                                             : (L.reproj_expw ? k_reproj_build_img<false, true> : k_reproj_build_img<false, false>));
           hipLaunchKernelGGL(kb, dim3(L.n_images), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.images.p, L.common.p, L.chain.p, L.jpart_base);
         }
         else {
