@@ -940,10 +940,18 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
     atab[i] = a;
   }
   // (i) coefficient band: task = (block column bj, block row bi = bj - d), ordered down the CCS column (d = 5 .. 0)
-  const int nband = 6 * nb;
+  // Only the pairs with bi >= 0 are numbered (block columns 0..4 have 1..5 of them): a chunk of 13 coefficient blocks has
+  // 63 tasks -- one wave -- where 6 nb = 78 put 14 lanes into a second wave that walked the rows for them alone.
+  auto band_task = [](int t, int& bj, int& d) {
+    if (t < 15) { bj = t >= 10 ? 4 : t >= 6 ? 3 : t >= 3 ? 2 : t >= 1 ? 1 : 0; d = bj - (t - (bj * (bj + 1)) / 2); }
+    else { bj = 5 + (t - 15) / 6; d = 5 - (t - 15 - 6 * (bj - 5)); }
+  };
+  const int nband = nb >= 5 ? 6 * nb - 15 : (nb * (nb + 1)) / 2;
   for (int base = 0; base < nband; base += 256) {
     const int t = base + tid;
-    const int bj = t / 6, d = 5 - (t - 6 * bj), bi = bj - d;
+    int bj, d;
+    band_task(t, bj, d);
+    const int bi = bj - d;
     double acc[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -979,9 +987,10 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
       const int e = 64 * p + lane, t2 = tb + e / 6, ra = e % 6;
-      const int bj2 = t2 / 6, d2 = 5 - (t2 - 6 * bj2);
+      int bj2, d2;
+      band_task(t2, bj2, d2);
       int slot = -1;
-      if (t2 < nband && bj2 - d2 >= 0) slot = band_slot[bj2 * 6 + d2];
+      if (t2 < nband) slot = band_slot[bj2 * 6 + d2];
       eaddr[p] = slot >= 0 ? slot + ra : -1;
       eh[p] = t2 < nband ? hcol[bj2] : 0;
       era[p] = d2 == 0 ? ra : -1;   // diagonal block: rows below the diagonal are not stored
