@@ -151,10 +151,9 @@ class BlockSparseCholesky {
     auto run = [&](int t) {
       const auto r0 = now();
       Work& wt = work[t];
-      if (wt.touched_hi >= wt.touched_lo)
-        std::fill(wt.top.begin() + (valptr_[wt.touched_lo] - top0), wt.top.begin() + (valptr_[wt.touched_hi + 1] - top0), 0.0);
+      for (int j = top_start_panel_; j < np_; ++j)
+        if (wt.hit[j]) { std::fill(wt.top.begin() + (valptr_[j] - top0), wt.top.begin() + (valptr_[j + 1] - top0), 0.0); wt.hit[j] = 0; }
       std::fill(wt.head.begin(), wt.head.end(), -1);
-      wt.touched_lo = np_; wt.touched_hi = -1;
       for (int j = top_start_panel_ + t; j < np_; j += P) preparePanel(j, Cx);     // the top's panels: shared out
       for (int j = part_start_[t]; j < part_start_[t + 1]; ++j) {
         double* Pj = Lx_.data() + valptr_[j];
@@ -179,7 +178,7 @@ class BlockSparseCholesky {
       double* Pj = Lx_.data() + valptr_[j];
       const size_t len = (size_t)m_[j] * dim_[j];
       for (int t = 0; t < P; ++t) {
-        if (j < work[t].touched_lo || j > work[t].touched_hi) continue;
+        if (!work[t].hit[j]) continue;
         const double* add = work[t].top.data() + (valptr_[j] - top0);
         for (size_t i = 0; i < len; ++i) Pj[i] += add[i];
       }
@@ -326,8 +325,9 @@ class BlockSparseCholesky {
   struct Work {
     std::vector<int> head, where;
     std::vector<double> top;
-    int touched_lo, touched_hi;
-    Work(int np, int nb, size_t top_size) : head(np, -1), where(nb, 0), top(top_size, 0.0), touched_lo(np), touched_hi(-1) {}
+    std::vector<char> hit;      // per panel: the part's image of it holds something (a part reaches the two separators next
+                                // to it and the dense blocks, a fraction of the top)
+    Work(int np, int nb, size_t top_size) : head(np, -1), where(nb, 0), top(top_size, 0.0), hit(np, 0) {}
   };
   // Left-looking step for panel j: P (the panel, or a private image of it) -= the products of the panels queued in
   // wk.head[j]; every one of them then moves on to the list of the panel of its next row block.  A queued panel k has
@@ -383,8 +383,8 @@ class BlockSparseCholesky {
     while (q > colptr_[k] && rowblk_[q - 1] >= top_start_) --q;      // rows are sorted: the top's are at the end
     while (q < pe) {
       const int j = pos_panel_[rowblk_[q]];
+      wk.hit[j] = 1;
       q = updateFrom(k, q, j, wk.top.data() + (valptr_[j] - top0), top_where_.data() + (size_t)(j - top_start_panel_) * (nb_ - top_start_) - top_start_);
-      wk.touched_lo = std::min(wk.touched_lo, j); wk.touched_hi = std::max(wk.touched_hi, j);
     }
   }
   // the finished panel j queues itself at the panel of its first row block below the diagonal block
