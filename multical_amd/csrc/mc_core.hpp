@@ -108,7 +108,7 @@ struct Batch {
 //   then n x (block index, dim, local column start, global column base)
 enum { OFP_HDR = 4 + MC_MAX_ROLES };
 // chunking limits: terms per chunk (rows must fit the LDS tile) and the target coefficient window
-enum { CHUNK_TERMS_LIDAR = 160, CHUNK_TERMS_IMU = 40, CHUNK_WINDOW = 40, CHUNK_BIAS_WINDOW = 8 };  // terms: two workgroups per CU by LDS (the kernels sit at 2 waves/SIMD by registers anyway); measured 128->160: -6 %, 32->40: -3 %, 48: 1 workgroup per CU, +40 %
+enum { CHUNK_TERMS_LIDAR = 160, CHUNK_TERMS_IMU = 40, CHUNK_TERMS_IMU_COMPACT = 50, CHUNK_WINDOW = 40, CHUNK_BIAS_WINDOW = 8 };  // terms: two workgroups per CU by LDS (the kernels sit at 2 waves/SIMD by registers anyway); measured 128->160: -6 %, 32->40: -3 %, 48: 1 workgroup per CU, +40 %
 
 // footprint layout in the flat int array `fp_data` at fp_off[f]:
 //   [0] nb   [1] C (local columns)   [2] first buffered spline coefficient, [3] number of buffered coefficients (time-offset kinds)
@@ -510,7 +510,9 @@ inline void Problem::finalize() {
       b.flops_dense = b.flops_live = 0;
       const SplineRec* bs = (!lidar && b.bias_spline >= 0) ? &splines[b.bias_spline] : nullptr;
       const int bias_block0 = bs ? dvs[bs->first_dv].block : -1;
-      int maxTerms = lidar ? (int)CHUNK_TERMS_LIDAR : (int)CHUNK_TERMS_IMU;
+      // IMU rows without a general sqrtInvR are stored with compact bias columns (152 instead of 216 doubles per term on the
+      // calibration problems; k_stream<.., CB>): 50 terms fit where 40 plain ones do (measured 44: 0.42, 48-54: 0.39, 56: 0.59 ms)
+      int maxTerms = lidar ? (int)CHUNK_TERMS_LIDAR : b.S.empty() ? (int)CHUNK_TERMS_IMU_COMPACT : (int)CHUNK_TERMS_IMU;
       if (const char* ov = std::getenv(lidar ? "MC_CHUNK_TERMS_LIDAR" : "MC_CHUNK_TERMS_IMU")) maxTerms = std::max(1, std::min(256, atoi(ov)));   // tuning aid
       // batch-level other roles
       std::vector<std::pair<int, int>> fixedRoles;  // (role, dv)

@@ -685,7 +685,8 @@ __device__ __forceinline__ int b_pose_first_col(const ImuBatchView& b) { return 
 //            rows): v_mfma_f64_16x16x4 has the same peak as the vector unit on this part and the band fills only half
 //            of each tile, so it ran 2-3x slower than the vector gathers.
 // Compared with one group per footprint this cuts the atomics by the number of terms that share a window.
-struct StreamDims { int maxT, maxNb, maxNob, maxG, ld, maxTab; };
+struct StreamDims { int maxT, maxNb, maxNob, maxG, ld, maxTab;
+                    int ldc, nbp; };   // compact-bias layout (IMU): row stride, doubles per term behind the rows
 template <class View> struct StreamBatch {
   View v;
   const int* order;      // time-sorted term order of the batch
@@ -734,6 +735,7 @@ template <> struct StreamTraits<LidarBatchView> {
     for (int i = 0; i < 6; ++i) x[i] = w * y[i];
   }
   // returns beta0 (>= 0) or -1 after setting *st
+  template <bool CB = false>
   static __device__ __forceinline__ int eval(const LidarBatchView& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int term_lo, int term_nbuf,
                                              double* J, int ld, double* e, TermOut& out, int* st) {
@@ -772,22 +774,30 @@ template <> struct StreamTraits<ImuBatchView> {
     coef6(row, o, x);
     coef6(row, o2, y);
   }
+  // CB: compact bias columns -- the bias columns are not stored in the rows (the columns behind them move down by their
+  // number) and the role column of the bias is the index of the first live coefficient in the term's bias-weight array
+  template <bool CB = false>
   static __device__ __forceinline__ int eval(const ImuBatchView& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int, int,
                                              double* J, int ld, double* e, TermOut& out, int* st) {
     int rc[MC_MAX_ROLES];
+    const int bias_0 = of[4 + IMU_ROLE_BIAS], bias_n = bias_0 >= 0 ? 3 * (b.bias.order > 0 ? of[3] : 1) : 0;
 #pragma unroll
-    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? CO + of[4 + r] : -1;
+    for (int r = 0; r < MC_MAX_ROLES; ++r) {
+      const int c = of[4 + r];
+      rc[r] = c >= 0 ? CO + ((CB && bias_0 >= 0 && c > bias_0) ? c - bias_n : c) : -1;
+    }
     const double t = b.t[u];
     if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     int beta0 = 0;
     rc[IMU_ROLE_POSE] = -1;
     if (pose_nb > 0) { beta0 = spline_segment(b.pose, t) - pose_lo; rc[IMU_ROLE_POSE] = 0; }
+    if (CB && rc[IMU_ROLE_BIAS] >= 0) rc[IMU_ROLE_BIAS] = 0;
     if (b.bias.order > 0 && rc[IMU_ROLE_BIAS] >= 0) {
       if (!(t >= b.bias.t_min && t <= b.bias.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
-      rc[IMU_ROLE_BIAS] += 3 * (spline_segment(b.bias, t) - of[2]);
+      rc[IMU_ROLE_BIAS] += (CB ? 1 : 3) * (spline_segment(b.bias, t) - of[2]);
     }
-    if (!imu_term(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    if (!imu_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     return beta0;
   }
 };
@@ -809,27 +819,35 @@ template <> struct StreamTraits<ImuSmBatchView> {
     coef6(row, o, x);
     coef6(row, o2, y);
   }
+  // CB: compact bias columns -- the bias columns are not stored in the rows (the columns behind them move down by their
+  // number) and the role column of the bias is the index of the first live coefficient in the term's bias-weight array
+  template <bool CB = false>
   static __device__ __forceinline__ int eval(const ImuSmBatchView& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int, int,
                                              double* J, int ld, double* e, TermOut& out, int* st) {
     int rc[MC_MAX_ROLES];
+    const int bias_0 = of[4 + IMU_ROLE_BIAS], bias_n = bias_0 >= 0 ? 3 * (b.bias.order > 0 ? of[3] : 1) : 0;
 #pragma unroll
-    for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? CO + of[4 + r] : -1;
+    for (int r = 0; r < MC_MAX_ROLES; ++r) {
+      const int c = of[4 + r];
+      rc[r] = c >= 0 ? CO + ((CB && bias_0 >= 0 && c > bias_0) ? c - bias_n : c) : -1;
+    }
     const double t = b.t[u];
     if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     int beta0 = 0;
     rc[IMU_ROLE_POSE] = -1;
     if (pose_nb > 0) { beta0 = spline_segment(b.pose, t) - pose_lo; rc[IMU_ROLE_POSE] = 0; }
+    if (CB && rc[IMU_ROLE_BIAS] >= 0) rc[IMU_ROLE_BIAS] = 0;
     if (b.bias.order > 0 && rc[IMU_ROLE_BIAS] >= 0) {
       if (!(t >= b.bias.t_min && t <= b.bias.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
-      rc[IMU_ROLE_BIAS] += 3 * (spline_segment(b.bias, t) - of[2]);
+      rc[IMU_ROLE_BIAS] += (CB ? 1 : 3) * (spline_segment(b.bias, t) - of[2]);
     }
-    if (!imu_sm_term(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    if (!imu_sm_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     return beta0;
   }
 };
 
-template <class View, bool BUILD>
+template <class View, bool BUILD, bool CB = false>
 __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
                                                 const ChunkRec* __restrict__ chunks, StreamDims dm, int jpart_base) {
   extern __shared__ double smem[];
@@ -843,10 +861,17 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
   const int* of = dc.ofp_data + dc.ofp_off[ch.ofp];
   const int nob = of[0], G = of[1];
   const int* oblk = of + OFP_HDR;   // nob x (block index, dim, local column start, global column base)
-  const int nb = ch.pose_nb, T = ch.term_count, ld = dm.ld;
+  // CB (IMU kinds without a general sqrtInvR): the 3 x bias_n bias entries of a term are nbc values (w_i on the diagonal of
+  // a 3 x 3 block, the same in the three rows); they are kept once per term behind its rows and the rows hold the other
+  // Gs = G - bias_n columns only: 152 instead of 216 doubles per term on the calibration problems
+  const int nb = ch.pose_nb, T = ch.term_count, ld = CB ? dm.ldc : dm.ld;
+  const int TS = D * ld + (CB ? dm.nbp : 0);   // doubles per term
+  int cb_0 = -1, cb_n = 0;                     // first bias column among the footprint's others, their number
+  if constexpr (CB) { cb_0 = of[4 + IMU_ROLE_BIAS]; cb_n = cb_0 >= 0 ? 3 * (b.bias.order > 0 ? of[3] : 1) : 0; }
+  const int Gs = G - cb_n;                     // other columns stored in a row
   const int pb = nb > 0 ? b_pose_first_block(b) + ch.pose_lo : 0;
   double* rows = smem;
-  int* ip = (int*)(rows + (size_t)dm.maxT * D * ld);
+  int* ip = (int*)(rows + (size_t)dm.maxT * TS);
   int* beta0 = ip; ip += dm.maxT;
   int* rlo = ip; ip += dm.maxNb + 1;
   int* rhi = ip; ip += dm.maxNb + 1;
@@ -863,7 +888,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
   __shared__ double red[4];
   constexpr bool build = BUILD;
   if (build) {
-    for (int i = tid; i < T * D * ld; i += 256) rows[i] = 0.0;
+    for (int i = tid; i < T * TS; i += 256) rows[i] = 0.0;
     for (int i = tid; i <= nb; i += 256) { rlo[i] = 0x7fffffff; rhi[i] = 0; }
     for (int i = tid; i < ch.tab_len; i += 256) tab[i] = dc.chunk_tab[ch.tab_off + i];
     __syncthreads();
@@ -877,15 +902,15 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
     double e[D];
     TermOut out;
     int st = 0;
-    double* Jrow = rows + (size_t)tid * D * ld;
-    int b0 = StreamTraits<View>::eval(b, dc.x, u, dc.useM != 0, build, of, ch.pose_lo, nb, term_lo[u], term_nbuf[u], Jrow, ld, e, out, &st);
+    double* Jrow = rows + (size_t)tid * TS;
+    int b0 = StreamTraits<View>::template eval<CB>(b, dc.x, u, dc.useM != 0, build, of, ch.pose_lo, nb, term_lo[u], term_nbuf[u], Jrow, ld, e, out, &st);
     if (b0 >= 0) {
       Jacc = out.w * out.chi2;
       dc.chi2[b.term_base_global + u] = out.chi2;
 #pragma unroll
       for (int r = 0; r < D; ++r) {
         if (dc.e) dc.e[b.row_base + D * u + r] = -e[r];
-        if (build) Jrow[r * ld + CO + G] = e[r];
+        if (build) Jrow[r * ld + CO + Gs] = e[r];
       }
       if (build) {
         beta0[tid] = b0;
@@ -928,7 +953,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
   __shared__ double wstrip[4][32 * 6];
   const int lane = tid & 63, wave = tid >> 6;
   double* strip = wstrip[wave];
-  const int rstride = D * ld;
+  const int rstride = TS;
   const int smax = max(nb - S6, 0);   // last possible first live block
   // turn6: every lane hands in 6 values; emit(p, v) receives element e = 64 p + lane (p = 0..5) of the wave's 384 values
   // (element 6 l + i = value i of lane l).  Half a wave at a time through the 32 x 6 strip; LDS accesses of one wave
@@ -1025,7 +1050,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
   // (ii) coefficient x other columns (and the coefficient part of rhs: other column G = residual).
   // task = (tile of 4 other columns, coefficient block bi), consecutive lanes = consecutive blocks
   constexpr int GT = 4;
-  const int ngt = (G + 1 + GT - 1) / GT;
+  const int ngt = (Gs + 1 + GT - 1) / GT;        // over the stored columns
   const int narrow = nb > 0 ? ngt * nb : 0;
   for (int base = 0; base < narrow; base += 256) {
     const int t = base + tid;
@@ -1058,25 +1083,76 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
     }
     if (MC_MODE(dc) != 1) { if (acc[0][0] + acc[5][GT - 1] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
     const int tb = base + 64 * wave;
-    int eq[6], eg[6], ebi[6], era[6];
+    int eg[6], ebi[6], era[6];
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
       const int e = 64 * p + lane, t2 = tb + e / 6;
       const int gt2 = t2 / max(nb, 1);
-      era[p] = e % 6; ebi[p] = t2 - gt2 * nb; eg[p] = t2 < narrow ? GT * gt2 : G + 1; eq[p] = GT * gt2 * nb + ebi[p];
+      era[p] = e % 6; ebi[p] = t2 - gt2 * nb; eg[p] = t2 < narrow ? GT * gt2 : Gs + 1;
     }
     const int rhs0 = b_pose_first_col(b) + 6 * ch.pose_lo;
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       const double v6[6] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], acc[5][j]};
       turn6(v6, [&](int p, double v) {
-        const int g = eg[p] + j;
-        if (v == 0.0 || g > G) return;
-        if (g == G) { atomic_add_f64(dc.rhs + rhs0 + 6 * ebi[p] + era[p], -v); return; }
-        const int a = atab[eq[p] + j * nb];
+        const int gs = eg[p] + j;                  // stored column
+        if (v == 0.0 || gs > Gs) return;
+        if (gs == Gs) { atomic_add_f64(dc.rhs + rhs0 + 6 * ebi[p] + era[p], -v); return; }
+        const int g = (CB && cb_0 >= 0 && gs >= cb_0) ? gs + cb_n : gs;   // its number among the footprint's columns
+        const int a = atab[g * nb + ebi[p]];
         if (a >= 0) atomic_add_f64(dc.Cx + a + era[p], v);                                                                  // column = other
         else if (a < -1) atomic_add_f64(dc.Cx + (-2 - a) + era[p] * hcol[ebi[p]] + (era[p] * (era[p] + 1)) / 2, v);         // column = coefficient
       });
+    }
+  }
+  // (ii b) compact bias columns: task = (bias coefficient ci, coefficient block bi), a 6 x 3 tile whose column c collects
+  // residual row c only: 18 multiply-adds per term where the plain layout spends 72 on a 6 x 4 tile that is two thirds zeros
+  if constexpr (CB) {
+    const int nbc = cb_n / 3, nbias = nb > 0 ? nbc * nb : 0;
+    for (int base = 0; base < nbias; base += 256) {
+      const int t = base + tid;
+      const int ci = t / max(nb, 1), bi = t - ci * nb;
+      double acc[6][3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
+      if (t < nbias) {
+        for (int sg = max(0, bi - 5); sg <= min(bi, smax); ++sg) {
+          const int o = bi - sg, k1 = fge[sg + 1];
+          const double* px = rows + (size_t)fge[sg] * rstride;
+#pragma unroll MC_GATHER_UNROLL
+          for (int k = fge[sg]; k < k1; ++k, px += rstride) {
+            const double w = px[D * ld + ci];
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+              double xv[6];
+              StreamTraits<View>::coef6(px + r * ld, o, xv);
+#pragma unroll
+              for (int i = 0; i < 6; ++i) acc[i][r] += xv[i] * w;
+            }
+          }
+        }
+      }
+      if (MC_MODE(dc) != 1) { if (acc[0][0] + acc[5][2] == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+      const int tb = base + 64 * wave;
+      int ecol[6], ebi[6], era[6];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const int e = 64 * p + lane, t2 = tb + e / 6;
+        const int ci2 = t2 / max(nb, 1);
+        era[p] = e % 6; ebi[p] = t2 - ci2 * nb; ecol[p] = t2 < nbias ? cb_0 + 3 * ci2 : -1;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double v6[6] = {acc[0][c], acc[1][c], acc[2][c], acc[3][c], acc[4][c], acc[5][c]};
+        turn6(v6, [&](int p, double v) {
+          if (v == 0.0 || ecol[p] < 0) return;
+          const int a = atab[(ecol[p] + c) * nb + ebi[p]];
+          if (a >= 0) atomic_add_f64(dc.Cx + a + era[p], v);                                                                  // column = bias
+          else if (a < -1) atomic_add_f64(dc.Cx + (-2 - a) + era[p] * hcol[ebi[p]] + (era[p] * (era[p] + 1)) / 2, v);         // column = coefficient
+        });
+      }
     }
   }
   MC_MARK(pslot + 4);   // coefficient x other
@@ -1106,6 +1182,40 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
     }
   };
   const int G1 = G + 1;
+  if constexpr (CB) {
+    // place of column g (of the footprint's numbering; G = residual) in a term: inside row r, or in the bias weights
+    auto place = [&](int g, int r) {
+      if ((unsigned)(g - cb_0) < (unsigned)cb_n) return D * ld + (g - cb_0) / 3;
+      return r * ld + CO + (g >= cb_0 + cb_n && cb_0 >= 0 ? g - cb_n : g);
+    };
+    for (int idx = tid; idx < G1 * G1; idx += 256) {
+      const int g2 = idx / G1, g1 = idx - g2 * G1;
+      if (g1 > g2 || g1 == G) continue;
+      const int c1 = (unsigned)(g1 - cb_0) < (unsigned)cb_n ? (g1 - cb_0) % 3 : -1;
+      const int c2 = (unsigned)(g2 - cb_0) < (unsigned)cb_n ? (g2 - cb_0) % 3 : -1;
+      if (c1 >= 0 && c2 >= 0 && c1 != c2) continue;
+      const int only = c1 >= 0 ? c1 : c2;
+      double acc = 0.0;
+      if (only >= 0) {
+        const double* t1 = rows + place(g1, only);
+        const double* t2 = rows + place(g2, only);
+#pragma unroll 8
+        for (int k = 0; k < T; ++k, t1 += rstride, t2 += rstride) acc += *t1 * *t2;
+      } else {
+        const int p1 = place(g1, 0), p2 = place(g2, 0);
+        const double* trm = rows;
+#pragma unroll 4
+        for (int k = 0; k < T; ++k, trm += rstride) {
+#pragma unroll
+          for (int r = 0; r < D; ++r) acc += trm[r * ld + p1] * trm[r * ld + p2];
+        }
+      }
+      if (MC_MODE(dc) != 1) { if (acc == 1.2345e-300) dc.rhs[0] = 1.0; continue; }
+      oo_flush(g1, g2, acc);
+    }
+    MC_MARK(pslot + 5);   // other x other
+    return;
+  }
   const int bias_0 = StreamTraits<View>::biasColumns(b, of, bias_n_);
   const int bias_n = bias_n_;
   for (int idx = tid; idx < G1 * G1; idx += 256) {
@@ -1742,6 +1852,8 @@ struct LaunchUnit {
   DevBuf<F1Common> common;   // per image observation, rewritten by k_obs_common before every k_reproj
   DevBuf<F1Chain> chain;     // per image observation: matrix of the chain below the camera (build passes)
   bool reproj_equi = false, reproj_expw = false;   // any equidistant camera / any Blake-Zisserman batch in the launch
+  bool compact_bias = true;                        // IMU launches: no batch with a general sqrtInvR (k_stream<.., CB = true>)
+  int max_gs = 0, max_nbc = 0;                     // IMU launches: stored other columns / bias coefficients per chunk, at most
   DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time; F2: runs of observations of one camera
   int n_images = 0;
   int static_ld = 0;         // F2: row stride of the LDS tile
@@ -1942,6 +2054,15 @@ void mc_context::uploadStructure() {
       dm.maxT = std::max(dm.maxT, b.max_terms); dm.maxNb = std::max(dm.maxNb, b.max_nb);
       dm.maxNob = std::max(dm.maxNob, b.max_nob); dm.maxG = std::max(dm.maxG, b.max_g);
       dm.maxTab = std::max(dm.maxTab, b.max_tab);
+      if (li == LAUNCH_IMU || li == LAUNCH_IMU_SM) {
+        if (!b.S.empty()) L.compact_bias = false;
+        for (const ChunkRec& c : b.my_chunks) {
+          const int* of = &P.ofp_data[P.ofp_off[c.ofp]];
+          const int bias_0 = of[4 + IMU_ROLE_BIAS], nbc = bias_0 >= 0 ? (b.bias_spline >= 0 ? of[3] : 1) : 0;
+          L.max_gs = std::max(L.max_gs, of[1] - 3 * nbc);
+          L.max_nbc = std::max(L.max_nbc, nbc);
+        }
+      }
     } else if (b.kind != KIND_MOTION) {
       double last_time = 0;
       bool first_of_batch = true;
@@ -2110,16 +2231,21 @@ void mc_context::uploadStructure() {
       // coefficient columns (36 live ones; lidar: 12, rank-one form) + (other columns + residual) padded to whole 4-column tiles
       dm.ld = (l == LAUNCH_LIDAR ? 12 : 36) + ((dm.maxG + 1 + 3) / 4) * 4;
       const int dim = l == LAUNCH_LIDAR ? 1 : 3;
+      const bool cb = l != LAUNCH_LIDAR && L.compact_bias && std::getenv("MC_IMU_PLAIN_ROWS") == nullptr;
+      L.compact_bias = cb;
+      dm.ldc = 36 + ((L.max_gs + 1 + 3) / 4) * 4;
+      dm.nbp = (L.max_nbc + 1) & ~1;
+      const size_t term_doubles = cb ? (size_t)dim * dm.ldc + dm.nbp : (size_t)dim * dm.ld;
       size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + dm.maxTab + (size_t)dm.maxG * dm.maxNb + 4;
-      L.lds_bytes = (int)((size_t)dm.maxT * dim * dm.ld * sizeof(double) + ints * sizeof(int) + 16);
+      L.lds_bytes = (int)((size_t)dm.maxT * term_doubles * sizeof(double) + ints * sizeof(int) + 16);
       if (L.lds_bytes > 150 * 1024) throw std::runtime_error("chunk tile exceeds the LDS budget");
       if (L.lds_bytes > 64 * 1024) {
         if (l == LAUNCH_LIDAR)
           HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<LidarBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
         else if (l == LAUNCH_IMU_SM)
-          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<ImuSmBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+          HIP_CHECK(hipFuncSetAttribute(cb ? (const void*)k_stream<ImuSmBatchView, true, true> : (const void*)k_stream<ImuSmBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
         else
-          HIP_CHECK(hipFuncSetAttribute((const void*)k_stream<ImuBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+          HIP_CHECK(hipFuncSetAttribute(cb ? (const void*)k_stream<ImuBatchView, true, true> : (const void*)k_stream<ImuBatchView, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
       }
     } else {
       L.groups.upload(groups[l]);
@@ -2227,7 +2353,8 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
         else hipLaunchKernelGGL(k_static<false>, dim3(L.n_images), dim3(256), 0, st, L.sviews.p, dc, L.groups.p, L.images.p, L.common2.p, L.static_ld, L.jpart_base);
         break;
       case LAUNCH_IMU:
-        if (build) hipLaunchKernelGGL((k_stream<ImuBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        if (build && L.compact_bias) hipLaunchKernelGGL((k_stream<ImuBatchView, true, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else if (build) hipLaunchKernelGGL((k_stream<ImuBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         else hipLaunchKernelGGL((k_stream<ImuBatchView, false>), dim3(L.n_items), dim3(std::min(256, (L.dims.maxT + 63) & ~63)), 0, st, L.iviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_LIDAR:
@@ -2235,7 +2362,8 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
         else hipLaunchKernelGGL((k_stream<LidarBatchView, false>), dim3(L.n_items), dim3(std::min(256, (L.dims.maxT + 63) & ~63)), 0, st, L.lviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_IMU_SM:
-        if (build) hipLaunchKernelGGL((k_stream<ImuSmBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        if (build && L.compact_bias) hipLaunchKernelGGL((k_stream<ImuSmBatchView, true, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
+        else if (build) hipLaunchKernelGGL((k_stream<ImuSmBatchView, true>), dim3(L.n_items), dim3(256), L.lds_bytes, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         else hipLaunchKernelGGL((k_stream<ImuSmBatchView, false>), dim3(L.n_items), dim3(std::min(256, (L.dims.maxT + 63) & ~63)), 0, st, L.xviews.p, dc, L.chunks.p, L.dims, L.jpart_base);
         break;
       case LAUNCH_GYRO_PRIOR:

@@ -390,6 +390,9 @@ MC_HD void body_rate(const PoseSample& ps, const double* v, double* rate, double
 #pragma unroll
   for (int i = 0; i < 9; ++i) { G0[i] = -CD[i] - KC[i]; G1[i] = -CbwS[i]; }
 }
+// CB (stream kernel, no general sqrtInvR): the bias columns of the three rows hold one value per live bias coefficient
+// (w_i on the diagonal of a 3 x 3 block), so it is written once, behind the rows: J[3 ld + rolecol[BIAS] + i]
+template <bool CB = false>
 MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol, double* J,
                     int ld, double* e, TermOut& out) {
   double t = b.t[k];
@@ -463,7 +466,10 @@ MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bo
   }
   // bias: w^b_i * I  (BSplineEuclideanExpressionNode, BSplineExpressions.cpp:589-599) or I (static EuclideanPoint)
   if (rolecol[IMU_ROLE_BIAS] >= 0) {
-    if (b.bias.order > 0) {
+    if (CB) {
+      if (b.bias.order > 0) { for (int i = 0; i < S6; ++i) J[3 * ld + rolecol[IMU_ROLE_BIAS] + i] = sw * b.bias_scale * bw[0][i]; }
+      else J[3 * ld + rolecol[IMU_ROLE_BIAS]] = sw * b.bias_scale;
+    } else if (b.bias.order > 0) {
       for (int i = 0; i < S6; ++i)
         for (int r = 0; r < 3; ++r)
           for (int c = 0; c < 3; ++c) J[r * ld + rolecol[IMU_ROLE_BIAS] + 3 * i + c] = (r == c) ? sw * b.bias_scale * bw[0][i] : 0.0;
@@ -589,6 +595,7 @@ MC_HD void m3_add_skew_product(const double* A, const double* v, double* acc) { 
 #pragma unroll
   for (int i = 0; i < 9; ++i) acc[i] += T[i];
 }
+template <bool CB = false>
 MC_HD bool imu_sm_term(const ImuSmBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol, double* J,
                        int ld, double* e, TermOut& out) {
   const double t = b.t[k];
@@ -668,7 +675,10 @@ MC_HD bool imu_sm_term(const ImuSmBatchView& b, const double* x, int k, bool use
 
   // bias
   if (rolecol[IMU_ROLE_BIAS] >= 0) {
-    if (b.bias.order > 0) {
+    if (CB) {
+      if (b.bias.order > 0) { for (int i = 0; i < S6; ++i) J[3 * ld + rolecol[IMU_ROLE_BIAS] + i] = sw * b.bias_scale * bw[0][i]; }
+      else J[3 * ld + rolecol[IMU_ROLE_BIAS]] = sw * b.bias_scale;
+    } else if (b.bias.order > 0) {
       for (int i = 0; i < S6; ++i)
         for (int r = 0; r < 3; ++r) J[r * ld + rolecol[IMU_ROLE_BIAS] + 3 * i + r] = sw * b.bias_scale * bw[0][i];
     } else {
