@@ -41,7 +41,7 @@ print(open(os.path.join("profiles", tag + "_pmc_hbm_traffic.csv")).read())
 
 # per-launch HBM bytes (fetch x2 + write) of the buildSystem kernels, for bench.py's roofline.traffic
 import json
-short = {"k_reproj_build": "k_reproj", "k_stream<mc::ImuBatchView, true>": "k_stream<Imu>", "k_stream<mc::LidarBatchView, true>": "k_stream<Lidar>",
+short = {"k_reproj_build": "k_reproj", "k_stream<mc::ImuBatchView, true": "k_stream<Imu>", "k_stream<mc::LidarBatchView, true": "k_stream<Lidar>",
          "k_motion(": "k_motion", "k_static<true>": "k_static"}
 out = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline", "unit": "bytes per launch", "kernels": {}}
 for k, a in agg.items():
