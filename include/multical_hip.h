@@ -165,6 +165,8 @@ int mc_add_motion_term(mc_context* ctx, int spline, const double* W, int error_t
  * partial results from different ranks add element-wise).  No counterpart in the reference, whose
  * only parallelism is boost threads over term ranges (LinearSystemSolver.cpp:50-78). */
 int mc_set_shard(mc_context* ctx, int rank, int world);
+/* the shard this context was given (0 of 1 without mc_set_shard) */
+int mc_shard_info(const mc_context* ctx, int* rank, int* world);
 
 /* With shards, only the value entries that more than one rank's terms can write need summing over ranks: the halos of
  * the coefficient band at the window boundaries and the blocks between global design variables (a few 10^5 values,
@@ -212,8 +214,9 @@ int mc_evaluate_error_and_build_system_device(mc_context* ctx, int use_mestimato
  * kernels, same results and same arguments as mc_build_system_device, but the scratch the build needs (the 16 replicas of
  * the contended global x global Hessian / rhs entries) lives in a file-scope __device__ array of the library (4.05 MiB,
  * held by every GPU the library runs on until the process ends) whose address is looked up once per device in mc_create,
- * every launch stays on `stream` (no side streams, no events are created), and the call makes no hipMalloc / hipFree /
- * allocating library call.  Limit: at most 256 scalar columns of global (non-spline) design variables; more is rejected
+ * every launch stays on `stream` (no side streams, no events are created; while `stream` is being captured the call
+ * records no event either, and the graph's owner orders its replays against the null-stream entry points such as
+ * mc_apply_update and mc_device_status itself), and the call makes no hipMalloc / hipFree / allocating library call.  Limit: at most 256 scalar columns of global (non-spline) design variables; more is rejected
  * with -1 and a message (problems with more than 512 such columns use no replicas and are accepted).  All contexts of a
  * process on one GPU share that GPU's array and the call clears what it uses: calls that overlap in time on one GPU
  * (different streams or threads) race on it -- serialise them. */

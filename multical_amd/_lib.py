@@ -46,6 +46,7 @@ SIGNATURES = {
     "mc_set_last_batch_sqrt_inv_r": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
     "mc_compute_matrix_sqrt": (C.c_int, [C.c_int, _dp, _dp]),
     "mc_set_shard": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "mc_shard_info": (C.c_int, [_ctx, _ip, _ip]),
     "mc_finalize": (C.c_int, [_ctx]),
     "mc_dims": (C.c_int, [_ctx, _ip, _ip, _ip, _ip, _ip]),
     "mc_dv_block": (C.c_int, [_ctx, C.c_int, _ip, _ip]),

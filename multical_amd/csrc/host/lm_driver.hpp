@@ -99,6 +99,10 @@ class FusedBlockEquations : public NormalEquations {
     for (int k = 0; k < 2; ++k) {
       detail::hipOk(hipMalloc((void**)&dH_[k], sizeof(double) * (size_t)nnz_), "hipMalloc(system values)");
       detail::hipOk(hipMalloc((void**)&dG_[k], sizeof(double) * (size_t)n_), "hipMalloc(gradient)");
+      // neither system is ever read before a trial has written it (trialPending_), but a zero system fails loudly where
+      // uninitialised memory would not
+      detail::hipOk(hipMemset(dH_[k], 0, sizeof(double) * (size_t)nnz_), "hipMemset(system values)");
+      detail::hipOk(hipMemset(dG_[k], 0, sizeof(double) * (size_t)n_), "hipMemset(gradient)");
     }
     detail::hipOk(hipMalloc((void**)&dCost_, sizeof(double)), "hipMalloc(cost)");
     detail::hipOk(hipHostMalloc((void**)&hH_, sizeof(double) * (size_t)nnz_, hipHostMallocDefault), "hipHostMalloc(system image)");
@@ -110,9 +114,16 @@ class FusedBlockEquations : public NormalEquations {
     double cost = 0.0;
     detail::hipOk(hipMemcpy(&cost, dCost_, sizeof(double), hipMemcpyDeviceToHost), "cost read-back");
     if (mc_device_status(ctx_) != 0) throw Exception(mc_last_error(ctx_));   // the reference throws out of evaluateError
+    trialPending_ = true;
     return cost;
   }
   void adopt() override {
+    // Only a trial's linearisation can be adopted.  Without a trial since the last adoption (Gauss-Newton after a failed
+    // factorisation: the reference's GaussNewtonTrustRegionPolicy rebuilds at the same state, fails the same way and stops
+    // at maxIterations with linearSolverFailure) the adopted system stays: flipping cur_ again would hand the step an
+    // older, or never written, device system.
+    if (!trialPending_) return;
+    trialPending_ = false;
     cur_ = 1 - cur_;
     detail::hipOk(hipMemcpy(hH_, dH_[cur_], sizeof(double) * (size_t)nnz_, hipMemcpyDeviceToHost), "system read-back");
     detail::hipOk(hipMemcpy(g_.data(), dG_[cur_], sizeof(double) * (size_t)n_, hipMemcpyDeviceToHost), "gradient read-back");
@@ -136,7 +147,7 @@ class FusedBlockEquations : public NormalEquations {
  private:
   void ok(int rc) const { if (rc < 0) throw Exception(mc_last_error(ctx_)); }
   mc_context* ctx_;
-  bool damped_ = true;
+  bool damped_ = true, trialPending_ = false;
   int n_ = 0, nnz_ = 0, cur_ = 0;
   double* dH_[2] = {nullptr, nullptr};
   double* dG_[2] = {nullptr, nullptr};

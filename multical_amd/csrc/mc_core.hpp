@@ -435,6 +435,14 @@ struct Problem {
   std::vector<std::vector<int>> fp_pattern;
   std::vector<std::vector<std::array<int, 3>>> fp_written;
 
+  // IMU launches: the compact-bias row layout needs every batch of the launch without a general sqrtInvR
+  bool imuLaunchCompact(int kind) const {
+    if (std::getenv("MC_IMU_PLAIN_ROWS") != nullptr) return false;
+    const bool sm = kind == KIND_ACCEL_SM || kind == KIND_GYRO_SM;
+    for (const Batch& o : batches)
+      if (kindIsImu(o.kind) && (o.kind == KIND_ACCEL_SM || o.kind == KIND_GYRO_SM) == sm && !o.S.empty()) return false;
+    return true;
+  }
   void finalize();
   void jtPattern(std::vector<int>& col_ptr, std::vector<int>& row_ind) const;
 };
@@ -512,7 +520,10 @@ inline void Problem::finalize() {
       const int bias_block0 = bs ? dvs[bs->first_dv].block : -1;
       // IMU rows without a general sqrtInvR are stored with compact bias columns (152 instead of 216 doubles per term on the
       // calibration problems; k_stream<.., CB>): 50 terms fit where 40 plain ones do (measured 44: 0.42, 48-54: 0.39, 56: 0.59 ms)
-      int maxTerms = lidar ? (int)CHUNK_TERMS_LIDAR : b.S.empty() ? (int)CHUNK_TERMS_IMU_COMPACT : (int)CHUNK_TERMS_IMU;
+      // The row layout is chosen per LAUNCH (uploadStructure: all calibrated-model batches share one k_stream launch, all
+      // scale-misalignment batches another): one batch with a general sqrtInvR, or MC_IMU_PLAIN_ROWS, turns the compact
+      // layout off for every batch of that launch, so the chunk size follows the launch, not the batch
+      int maxTerms = lidar ? (int)CHUNK_TERMS_LIDAR : imuLaunchCompact(b.kind) ? (int)CHUNK_TERMS_IMU_COMPACT : (int)CHUNK_TERMS_IMU;
       if (const char* ov = std::getenv(lidar ? "MC_CHUNK_TERMS_LIDAR" : "MC_CHUNK_TERMS_IMU")) maxTerms = std::max(1, std::min(256, atoi(ov)));   // tuning aid
       // batch-level other roles
       std::vector<std::pair<int, int>> fixedRoles;  // (role, dv)

@@ -204,7 +204,17 @@ inline void describeLandmarks(Problem& P, int n, const int* dv_lm) {
     throw std::invalid_argument("landmark design variables follow a static reprojection batch");
   Batch& b = P.batches.back();
   if (n != b.n_terms || !dv_lm) throw std::invalid_argument("one landmark id (or -1) per term of the batch");
-  for (int k = 0; k < n; ++k) if (dv_lm[k] >= 0) P.checkDv(dv_lm[k], DV_HOMOGENEOUS_POINT);
+  // the kernels carry ONE landmark scaling per batch (StaticReprojBatchView::lm_scale scales every landmark column of the
+  // batch), k_update applies each design variable's own: landmarks of one batch must share their DesignVariable::scaling()
+  double scaling = 0.0;
+  bool have = false;
+  for (int k = 0; k < n; ++k) {
+    if (dv_lm[k] < 0) continue;
+    P.checkDv(dv_lm[k], DV_HOMOGENEOUS_POINT);
+    const double s = P.dvs[dv_lm[k]].scaling;
+    if (have && s != scaling) throw std::invalid_argument("the landmark design variables of one batch must share one scaling()");
+    scaling = s; have = true;
+  }
   b.term_dv_lm.assign(dv_lm, dv_lm + n);
 }
 inline void describeMotion(Problem& P, int spline, const double* W, int order) {

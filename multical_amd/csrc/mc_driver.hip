@@ -30,6 +30,13 @@ void mc_optimizer_options_default(mc_optimizer_options* o) {
 int mc_optimize(mc_context* ctx, const mc_optimizer_options* opt, mc_solution_return_value* out) {
   try {
     if (!ctx || !opt || !out) throw Exception("mc_optimize: null argument");
+    {
+      // a sharded context returns this rank's partial cost, H and rhs: factorising those would apply a wrong step silently
+      int rank = 0, world = 1;
+      if (mc_shard_info(ctx, &rank, &world) == 0 && world > 1)
+        throw Exception("mc_optimize drives one unsharded context; with mc_set_shard(world > 1) use mc_optimize_sharded, "
+                        "which sums the shared entries, the gradient and the cost over the ranks between build and solve");
+    }
     MinimiserSettings cfg;
     cfg.stepTolerance = opt->convergenceDeltaX;
     cfg.costRatioTolerance = opt->convergenceJDescentRatioThreshold;

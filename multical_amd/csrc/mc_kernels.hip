@@ -1919,6 +1919,15 @@ struct mc_context {
   hipEvent_t ev_done = nullptr;
   bool done_recorded = false;
   void waitForLaunches() { if (done_recorded) HIP_CHECK(hipEventSynchronize(ev_done)); }
+  // End of a launch sequence.  Under stream capture nothing runs yet, and an event recorded into the capture cannot be
+  // waited for from the host (hipEventSynchronize rejects it): the graph's owner orders its replays against the
+  // null-stream entry points itself, so no event is recorded then and an earlier one stays valid.
+  void markDone(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return;
+    HIP_CHECK(hipEventRecord(ev_done, st));
+    done_recorded = true;
+  }
   ~mc_context() {
     for (int i = 0; i < N_SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -2405,8 +2414,7 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     }
     HIP_CHECK(hipGetLastError());
   }
-  HIP_CHECK(hipEventRecord(ev_done, st));
-  done_recorded = true;
+  markDone(st);
 }
 
 void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
@@ -2450,8 +2458,7 @@ void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
     hipLaunchKernelGGL(k_jt_stream<LidarBatchView>, dim3(L.n_items), dim3(128), 0, st, L.lviews.p, dc, L.chunks.p, jt);
   }
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipEventRecord(ev_done, st));
-  done_recorded = true;
+  markDone(st);
 }
 
 #define MC_TRY try {
@@ -2591,6 +2598,12 @@ int mc_set_shard(mc_context* ctx, int rank, int world) {
   ctx->P.rank = rank; ctx->P.world = world;
   return 0;
   MC_CATCH(ctx, -1)
+}
+int mc_shard_info(const mc_context* ctx, int* rank, int* world) {
+  if (!ctx) return -1;
+  if (rank) *rank = ctx->P.rank;
+  if (world) *world = ctx->P.world;
+  return 0;
 }
 int mc_finalize(mc_context* ctx) {
   MC_TRY ctx->P.finalize();

@@ -201,3 +201,36 @@ def test_levenberg_marquardt_to_convergence_matches_oracle():
         for i in range(0, W["pose_coeffs"].shape[1], 5):
             worst = max(worst, np.abs(g.dv_params(first + i) - o.dv_params(ofirst + i)).max())
     assert worst <= 1e-7, worst
+
+
+@pytest.mark.timeout(1200)
+def test_levenberg_marquardt_along_a_weakly_observable_direction_matches_oracle():
+    """The trajectory the convergence test above avoids: with motion_speed = 3.0 the same problem has a weakly observable
+    direction -- from iteration ~10 the cost creeps by ~1 per step while lambda falls to its floor -- and does not reach the
+    convergence thresholds in 40 iterations.  That creeping stretch is where GPU and oracle iterates would part first, so
+    the run is compared for a FIXED 40 iterations with no convergence assertion: same accepted / rejected sequence, JFinal
+    within 1e-9, estimates within 1e-7."""
+    from multical_amd import synth
+    from multical_amd.backend import HipApi
+    from oracle_lm import optimize_lm
+    cfg = synth.SynthConfig(duration=10.0, n_cams=2, n_imus=2, n_lidars=1, lidar_points_per_frame=40, corner_stride=4,
+                            cam_models=[(0, 1), (1, 1)], huber_accel=1.0, huber_gyro=1.0, blake_zisserman_cam=2,
+                            motion_speed=3.0)
+    spec, H, W, meas = synth.make_problem(cfg, lambda: HipApi(0))
+    g = HipApi(0)
+    ids = spec.emit(g)
+    o, oids = _oracle(spec)
+    iters = 40
+    r = g.optimize(maxIterations=iters, convergenceDeltaX=1e-5, convergenceJDescentRatioThreshold=1e-6,
+                   levenbergMarquardtLambdaInit=10.0)
+    ro = optimize_lm(o, iters, 10.0, 1e-5, 1e-6)
+    assert (r["iterations"], r["failedIterations"]) == (ro["iterations"], ro["failedIterations"]), (r, ro)
+    assert abs(r["JFinal"] - ro["JFinal"]) <= 1e-9 * ro["JFinal"], (r["JFinal"], ro["JFinal"])
+    worst = 0.0
+    for h, v in ids.items():
+        if isinstance(v, int) and spec.ops[h][0] == "dv":
+            worst = max(worst, np.abs(g.dv_params(v) - o.dv_params(oids[h])).max())
+    first, ofirst = g.spline_first_dv(ids[H["pose"]][1]), o.spline_first_dv(oids[H["pose"]][1])
+    for i in range(0, W["pose_coeffs"].shape[1], 5):
+        worst = max(worst, np.abs(g.dv_params(first + i) - o.dv_params(ofirst + i)).max())
+    assert worst <= 1e-7, worst

@@ -189,6 +189,32 @@ def test_gpu_levenberg_marquardt_matches_oracle(name):
         assert np.abs(g.dv_params(gids[H["bias"]]) - H["bias_true"]).max() < 5e-3
 
 
+@pytest.mark.gpu
+def test_gauss_newton_with_a_singular_system_fails_like_the_reference():
+    """A design variable no term touches leaves a zero diagonal block: without damping the factorisation fails.  The
+    reference's GaussNewtonTrustRegionPolicy rebuilds at the same state, fails the same way and stops at maxIterations
+    with linearSolverFailure set (Optimizer2.cpp:226-231); the state never moves.  (The minimiser must not adopt a
+    system no trial has written: csrc/host/lm_driver.hpp FusedBlockEquations::adopt.)"""
+    from multical_amd import spec as S
+    from multical_amd import synth_init as SI
+    from multical_amd.backend import HipApi
+    sp, H = SI.make_extrinsic_prior(n_gyro=60, n_other=0)
+    loose = sp.add_dv(S.DV_EUCLIDEAN_POINT, np.array([0.1, 0.2, 0.3]))   # active, in no error term
+    g = HipApi(0)
+    ids = sp.emit(g)
+    g.finalize()
+    before = {h: g.dv_params(v).copy() for h, v in ids.items() if isinstance(v, int) and sp.ops[h][0] == "dv"}
+    J0, _ = g.evaluate_error(True)
+    iters = 5
+    r = g.optimize(maxIterations=iters, trustRegionPolicy=1)
+    assert r["linearSolverFailure"] == 1
+    assert r["failedIterations"] == iters and r["iterations"] == 0
+    assert r["JStart"] == r["JFinal"] == J0
+    for h, v in before.items():
+        assert np.array_equal(g.dv_params(ids[h]), v), h
+    assert loose in before
+
+
 def test_front_end_mirror_lowers_the_initialisation_problems(problems):
     """The extrinsic-prior problem written statement by statement like findExtrinsicPriorSensorsToCamera
     (sensors_and_targets.py:858-919) and the target-pose problem like findTargetPosePrior (:803-817), through the

@@ -100,3 +100,55 @@ def test_full_size_structural_zeros_and_shards(full):
     assert np.abs(rhs_sum - rhs).max() <= 1e-12 * np.abs(rhs).max()
     # padded time-offset buffer blocks are in the pattern (the reference allocates them) but nothing is ever added
     assert (Cx == 0.0).sum() > 0.2 * g.nnz
+
+
+def test_bench_workload_itself_against_the_host_build():
+    """The system bench.py times -- configs[3] at full size WITH the M-estimators and the BSplineMotionError bias priors
+    (4.8 M terms) -- against the host build of the same closed forms (tests/hostprobe cpu_optimised, proven equal to the
+    oracle in test_product_math_cpu.py::test_cpu_optimised_baseline_equals_the_oracle): J, Cx, rhs at 1e-9 (entries of Cx
+    also against the scale of their own row and column), structural zeros exact.  The host build shares the term math with
+    the kernels but none of their reductions (chunk / tile windows, slot tables, atomics, replicas)."""
+    from multical_amd import synth
+    from multical_amd.backend import HipApi
+    from probe_api import ProbeApi
+    cfg = synth.baseline_config(3)
+    W = synth.make_world(cfg)
+    meas = synth.synthesize(W, lambda: HipApi(0), noise=True)
+    spec, H = synth.build_spec(W, synth.initial_state(W), meas)      # with_mest = True, motion priors on: bench.py's problem
+    g = HipApi(0)
+    spec.emit(g)
+    g.finalize()
+    assert g.n_terms > 4_000_000
+    p = ProbeApi()
+    spec.emit(p)
+    p.finalize()
+    Jp, Cxp, rhsp = p.cpu_optimised(True, True, 16)
+    Jg, _ = g.evaluate_error(True, want_e=False)
+    Cxg, rhsg = g.build_system(True)
+    g.check_status()
+    assert abs(Jg - Jp) <= 1e-9 * abs(Jp)
+    assert np.abs(rhsg - rhsp).max() <= 1e-9 * np.abs(rhsp).max()
+    assert np.abs(Cxg - Cxp).max() <= 1e-9 * np.abs(Cxp).max()
+    assert np.linalg.norm(Cxg - Cxp) <= 1e-9 * np.linalg.norm(Cxp)
+    Cp, Ci = g.pattern()
+    n = g.j_cols
+    col_of = np.repeat(np.arange(n, dtype=np.int32), np.diff(Cp))
+    cmax = np.zeros(n)
+    np.maximum.at(cmax, col_of, np.abs(Cxp))
+    rmax = np.zeros(n)
+    np.maximum.at(rmax, Ci, np.abs(Cxp))
+    tol = 1e-8 * np.sqrt(np.maximum(cmax[col_of], 1e-300) * np.maximum(np.maximum(rmax, cmax)[Ci], 1e-300))
+    assert np.all(np.abs(Cxg - Cxp) <= tol)
+    assert np.array_equal(Cxg == 0.0, Cxp == 0.0)
+    # the fused pass (what bench.py's step launches) gives the same system
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    dJ = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    dCx = torch.zeros(g.nnz, dtype=torch.float64, device="cuda:0")
+    drhs = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    g.evaluate_error_and_build_system_device(True, dJ.data_ptr(), None, dCx.data_ptr(), drhs.data_ptr(), st)
+    torch.cuda.synchronize()
+    g.check_status()
+    assert abs(float(dJ.item()) - Jp) <= 1e-9 * abs(Jp)
+    assert np.abs(dCx.cpu().numpy() - Cxp).max() <= 1e-9 * np.abs(Cxp).max()
+    assert np.abs(drhs.cpu().numpy() - rhsp).max() <= 1e-9 * np.abs(rhsp).max()

@@ -52,6 +52,26 @@ def test_noalloc_entry_point_matches_build_system_device_twice_in_a_row():
         assert np.abs(b2 - b).max() <= 1e-12 * np.abs(b).max() and np.abs(rb2 - rb).max() <= 1e-12 * np.abs(rb).max()
 
 
+def test_noalloc_entry_point_allocates_no_device_memory():
+    """hipMemGetInfo before and after the call (after a first call has loaded the kernels' code objects): the free device
+    memory does not move, while the allocating entry point is free to change it."""
+    import torch
+    from multical_amd import synth
+    g = _ctx(synth.SynthConfig(duration=2.0, n_cams=2, n_imus=1, n_lidars=1, lidar_points_per_frame=20, corner_stride=7))
+    st = torch.cuda.current_stream().cuda_stream
+    dCx = torch.zeros(g.nnz, dtype=torch.float64, device="cuda:0")
+    drhs = torch.zeros(g.j_cols, dtype=torch.float64, device="cuda:0")
+    g.build_system_device_noalloc(True, dCx.data_ptr(), drhs.data_ptr(), st)   # loads the code objects
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(3):
+        g.build_system_device_noalloc(True, dCx.data_ptr(), drhs.data_ptr(), st)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 == free0, (free0, free1)
+    g.check_status()
+
+
 def test_noalloc_entry_point_rejects_missing_outputs():
     from multical_amd import synth
     from multical_amd.backend import BackendError
