@@ -159,6 +159,40 @@ int orc_u_distort(int kind, const double* k, const double* y, double* yd, double
   return 0;
 }
 
+// quat2r (quaternion_algebra.cpp:77-101) and RotationVector::parametersToRotationMatrix (RotationVector.cpp:10-55): 3 x 3 row major
+int orc_u_quat2r(const double* q, double* R) {
+  Mat M = quat2r(Mat::Vec({q[0], q[1], q[2], q[3]}));
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = M(i, j);
+  return 0;
+}
+int orc_u_rv_rotation_matrix(const double* p, double* Cm) {
+  Mat M = rvRotationMatrix(Mat::Vec({p[0], p[1], p[2]}));
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Cm[3 * i + j] = M(i, j);
+  return 0;
+}
+// {Pinhole,Omni,DoubleSphere}Projection::euclideanToKeypoint with Jacobian, euclideanToKeypointIntrinsicsJacobian and
+// euclideanToKeypointDistortionJacobian of one point.  model 0 / 1 / 2, dist 0 / 1 / 2 as in ocam.hpp; proj in update()
+// order; kp[2], Jp 2 x 3, Ji 2 x projDims, Jd 2 x 4 (untouched without a distortion), all row major.  Returns e2k's flag.
+int orc_u_project(int model, int dist, const double* proj, const double* dk, const double* p, double* kp, double* Jp, double* Ji,
+                  double* Jd) {
+  Camera c;
+  c.model = model;
+  c.proj.assign(proj, proj + (model == PROJ_PINHOLE ? 4 : (model == PROJ_OMNI ? 5 : 6)));
+  c.dist.kind = dist;
+  for (int i = 0; i < 4; ++i) c.dist.k[i] = dist != DIST_NONE ? dk[i] : 0.0;
+  Mat J;
+  const bool ok = c.e2k(p, kp, &J);
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Jp[3 * i + j] = J(i, j);
+  Mat ph = Mat::Vec({p[0], p[1], p[2], 1.0});
+  Mat I = c.intrinsicsJacobian(ph);
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < c.projDims(); ++j) Ji[c.projDims() * i + j] = I(i, j);
+  if (dist != DIST_NONE) {
+    Mat D = c.distortionJacobian(ph);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) Jd[4 * i + j] = D(i, j);
+  }
+  return ok ? 1 : 0;
+}
+
 // aslam::calibration::OptimizationProblem (incremental_calibration/src/core/OptimizationProblem.cpp): the design-variable
 // enumeration Optimizer2::initialize walks.  addDesignVariable (:123-137) appends the variable to its group's vector and
 // the group id to _groupsOrdering on first sight; designVariable(idx) (:215-221) resolves idx through getGroupId (:272-292):

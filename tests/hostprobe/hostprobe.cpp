@@ -321,6 +321,17 @@ int probe_u_distort(int kind, const double* k, const double* y, double* yd, doub
   distort_param_jacobian(kind, y, Jk);
   return 0;
 }
+int probe_u_quat2r(const double* q, double* R) { quat2r(q, R); return 0; }
+int probe_u_rotvec_C(const double* th, double* Cm) { double S[9]; rotvec_C_S(th, Cm, S); return 0; }
+// project / intrinsics_jacobian / distortion_jacobian of mc_math.h for one point: kp[2], Jp 2 x 3, Ji 2 x projDims,
+// Jd 2 x 4 (untouched without a distortion), row major
+int probe_u_project(int model, int dist, const double* proj, const double* dk, const double* p, double* kp, double* Jp, double* Ji,
+                    double* Jd) {
+  project<true>(model, dist, proj, dk, p, kp, Jp);
+  intrinsics_jacobian(model, dist, proj, dk, p, Ji);
+  if (dist != 0) distortion_jacobian(model, dist, proj, p, Jd);
+  return 0;
+}
 // Q of the n-th BSplineMotionError batch (describeMotion's band) as a dense (D nc) x (D nc) row-major matrix
 int probe_motion_q(void* h, int which, double* out, int N) {
   Probe* pr = (Probe*)h;

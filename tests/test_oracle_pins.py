@@ -86,6 +86,65 @@ def test_equidistant_jacobians_against_the_reference_expression():
             assert np.abs(yd - y * thd / r).max() <= 1e-15
 
 
+CAMERA_PAIRS = [(0, 0, "pinhole_none"), (0, 1, "pinhole_radtan"), (0, 2, "pinhole_equi"), (1, 0, "omni_none"),
+                (1, 1, "omni_radtan"), (1, 2, "omni_equi"), (2, 0, "ds_none")]
+
+
+@pytest.mark.parametrize("model,dist,tag", CAMERA_PAIRS)
+def test_camera_models_against_the_reference_source(model, dist, tag):
+    """Rows E1, E2, E4, E5 (and E3 through the projections): keypoint, point Jacobian, intrinsics Jacobian and distortion
+    Jacobian of every projection x distortion pair of north_star, oracle AND product, against what the reference's own
+    straight-line code gives at the same inputs (PinholeProjection.hpp:123-141, 340-351; OmniProjection.hpp:147-177, 399-418;
+    DoubleSphereProjection.hpp:166-217, 460-501; RadialTangentialDistortion.hpp:47-63, 162-180; EquidistantDistortion.hpp:17-28,
+    54-170, 258-273 -- evaluated from the source text by tests/golden/make_reference_vectors.py)."""
+    g = np.load(GOLD)
+    o, p = _olib(), _plib()
+    pd = 4 + model
+    n = g["cam_%s_p" % tag].shape[0]
+    for k in range(n):
+        proj, dk, pt = _f64(g["cam_%s_proj" % tag][k]), _f64(g["cam_%s_dist" % tag][k]), _f64(g["cam_%s_p" % tag][k])
+        # the equidistant dump subtracts two terms of size 1 / r^2 near the optical axis (see the test above)
+        r = np.hypot(pt[0], pt[1]) / pt[2]
+        tol = max(1e-12, 1e-15 / r ** 2) if dist == 2 else 1e-12
+        for lib, fn in ((o, "orc_u_project"), (p, "probe_u_project")):
+            kp, Jp, Ji, Jd = np.zeros(2), np.zeros((2, 3)), np.zeros((2, pd)), np.zeros((2, 4))
+            getattr(lib, fn)(C.c_int(model), C.c_int(dist), _d(proj), _d(dk), _d(pt), _d(kp), _d(Jp), _d(Ji), _d(Jd))
+            for name, got in (("kp", kp), ("Jp", Jp), ("Ji", Ji), ("Jd", Jd)):
+                want = g["cam_%s_%s" % (tag, name)][k]
+                assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-300) + (0.0 if np.abs(want).max() > 0 else 1e-300), \
+                    (fn, tag, name, k, got, want)
+
+
+def test_radial_tangential_distortion_against_the_reference_source():
+    """Row E2 on its own: distort, its Jacobian (symmetric by construction, J(0,1) = J(1,0)) and distortParameterJacobian."""
+    g = np.load(GOLD)
+    o, p = _olib(), _plib()
+    for k in range(g["rt_y"].shape[0]):
+        y, kk = _f64(g["rt_y"][k]), _f64(g["rt_k"][k])
+        for lib, fn in ((o, "orc_u_distort"), (p, "probe_u_distort")):
+            yd, Jy, Jk = np.zeros(2), np.zeros((2, 2)), np.zeros((2, 4))
+            getattr(lib, fn)(C.c_int(1), _d(kk), _d(y), _d(yd), _d(Jy), _d(Jk))
+            assert np.abs(yd - g["rt_yd"][k]).max() <= 1e-14 * max(1.0, np.abs(g["rt_yd"][k]).max()), (fn, k)
+            assert np.abs(Jy - g["rt_Jy"][k]).max() <= 1e-13 * np.abs(g["rt_Jy"][k]).max(), (fn, k)
+            assert np.abs(Jk - g["rt_Jk"][k]).max() <= 1e-13 * np.abs(g["rt_Jk"][k]).max() + 1e-300, (fn, k)
+            assert Jy[0, 1] == Jy[1, 0]
+
+
+def test_quat2r_and_rodrigues_against_the_reference_source():
+    """Rows C7 / D4: quat2r's nine element formulas (quaternion_algebra.cpp:90-98) and the Rodrigues matrix of
+    RotationVector::parametersToRotationMatrix (RotationVector.cpp:31-43), oracle and product."""
+    g = np.load(GOLD)
+    o, p = _olib(), _plib()
+    for k in range(g["kin_q"].shape[0]):
+        q, th = _f64(g["kin_q"][k]), _f64(g["kin_rv"][k])
+        for lib, fq, fc in ((o, "orc_u_quat2r", "orc_u_rv_rotation_matrix"), (p, "probe_u_quat2r", "probe_u_rotvec_C")):
+            R, Cm = np.zeros((3, 3)), np.zeros((3, 3))
+            getattr(lib, fq)(_d(q), _d(R))
+            getattr(lib, fc)(_d(th), _d(Cm))
+            assert np.abs(R - g["kin_quat2r"][k]).max() <= 1e-15, (fq, k)
+            assert np.abs(Cm - g["kin_rv_C"][k]).max() <= 1e-14, (fc, k, np.linalg.norm(th))
+
+
 # ------------------------------------------------------------------------------------------ 2a. evalD == spalde
 def _spline_case(order, knots, rng):
     kr = knots.size
