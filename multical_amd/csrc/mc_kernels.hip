@@ -147,15 +147,42 @@ __device__ __forceinline__ int global_col(const FpView& f, int ca) {
 // F1 pre-pass: one LANE per image observation computes what all its corners share (spline sample at t + d, the
 // transformation chain prefixes).  Done inside k_reproj this would be repeated by every lane of the workgroup -- as
 // many flops as the corners themselves.
+// fp_data / fp_off / status (optional, the split build path): the observation's live support is checked against the buffer
+// frozen at construction here, once, and a failing observation is marked not ok for the kernels behind
+// what the owner tiles of k_reproj_assemble need of an observation besides G and the chain matrix, in one 64-byte line
+struct F1Lite { double w[S6]; int seg, ok; double pad; };
 __global__ __launch_bounds__(64) void k_obs_common(const ReprojBatchView* __restrict__ views, const double* __restrict__ x,
                                                    const GroupRec* __restrict__ groups, int n, F1Common* __restrict__ out,
-                                                   F1Chain* __restrict__ chain) {
+                                                   F1Chain* __restrict__ chain, const int* __restrict__ fp_data = nullptr,
+                                                   const int* __restrict__ fp_off = nullptr, int* __restrict__ status = nullptr,
+                                                   F1Lite* __restrict__ lite = nullptr) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const GroupRec gr = groups[g];
   F1Common cm;
   f1_common(views[gr.batch], x, gr.aux, cm);
+  if (status) {
+    if (!cm.ok) atomicOr(status, STATUS_TIME_OUT_OF_SPLINE);
+    else {
+      // live support must lie inside the buffer frozen at construction (BSplineExpressions.cpp:447,503)
+      const int* f = fp_data + fp_off[gr.fp];
+      const int shift = cm.seg - f[2];
+      if (f[4 + F1_ROLE_COEF] >= 0 && (shift < 0 || shift + S6 > f[3])) { atomicOr(status, STATUS_BUFFER_EXCEEDED); cm.ok = 0; }
+    }
+  }
   out[g] = cm;
+  if (lite) {
+    F1Lite l;
+#pragma unroll
+    for (int i = 0; i < S6; ++i) l.w[i] = cm.w[i];
+    l.seg = cm.seg; l.ok = cm.ok; l.pad = 0.0;
+    if (cm.seg < 0) {   // time outside the spline: keep the list ordered for k_f1_ranges (before the start / past the end)
+      const ReprojBatchView& b = views[gr.batch];
+      const double t = b.obs_time[gr.aux] + (b.toff.off >= 0 ? x[b.toff.off] : 0.0);
+      l.seg = t < b.sp.t_min ? -(1 << 30) : (1 << 30);
+    }
+    lite[g] = l;
+  }
   if (chain && cm.ok) f1_chain_matrix(views[gr.batch], cm, chain[g]);   // build passes only
 }
 
@@ -662,6 +689,293 @@ __global__ __launch_bounds__(256, (EQUI || EXPW) ? MC_RB_OCC : 4) void k_reproj_
   FpView f = last_info[4] ? fp_view_at(reinterpret_cast<const int*>(zs_all[lw] + O_FP)) : fp_view_at(dc.fp_data + last_info[5]);
   const F1Common& cml = *reinterpret_cast<const F1Common*>(cm_s[lo]);
   f1_flush(f, dc, Mimg, cml.w, last_info[1], last_info[2], gl_all[lw][0], gl_all[lw][1], gl_all[lw][2], last_info[3], last_info[3], false, tid, 256);
+}
+
+// ---------------------------------------------------------------------------------------------
+// buildSystem for F1, third shape (round 3): evaluation split from assembly, assembly by OWNER.
+//   k_reproj_gram      lane = corner over the whole launch, no image structure: a wave takes 64 consecutive corners of one
+//                      camera (they may belong to several observations), projects them and reduces the 7 x 7 Gram of
+//                      [a, a x p_c | residual] of every observation present on the fp64 matrix cores, rows of the other
+//                      observations masked to zero, into the observation's G in global memory (49 doubles, a handful of
+//                      contiguous fp64 atomics per wave).  Nothing else leaves the kernel: 30 KB of LDS, no barrier in the
+//                      loop, every SIMD busy -- the per-image workgroup of the second shape spent most of its time in
+//                      dependent loads and barriers with 1.6 corners per lane.
+//   k_f1_ranges        per camera: first observation whose spline segment (at the CURRENT time offset) reaches a tile
+//                      boundary; the observations of a camera are time sorted, so a binary search per boundary.
+//   k_reproj_assemble  a workgroup OWNS K consecutive pose-coefficient blocks: the band columns of those blocks and their
+//                      rows in every global design variable's columns.  It pulls the observations whose live window
+//                      touches its blocks (segments c0 - 5 .. c0 + K - 1; an observation is expanded by up to two
+//                      owners, the expansion is ~3 k multiply-adds), forms M = Kt^T G Kt per observation, adds
+//                      w_i w_j M into LDS accumulators and leaves with PLAIN read-modify-write stores: no atomic touches
+//                      the coefficient band or the coefficient x global entries.  Entries between two global design
+//                      variables (every observation writes them) still go to the replicas, from the observation's
+//                      primary owner only.  Runs after the other families' kernels have joined (its stores are not atomic).
+struct F1Pass { int batch, term_first, n_terms, obs_first, n_obs; };
+// static per observation: its global live columns in core order (q_c_b, t_c_b, q_p_w, t_p_w, time offset; inactive ones
+// left out): footprint-local column, core column, compact global column of the replicas (-1: none), accumulator column
+struct F1ObsTab { int n_glob, has_coef, pad0, pad1; int glc[13], gk[13], ggc[13], acol[13]; };
+struct F1Asm {
+  int K, n_tiles, ncol, nGB, n_batches;
+  int pose_block0, pose_col0;
+  const int* band;    // [n_tiles][K * 6]  value offset of block pair (c0 + k - d, c0 + k), -1 if absent
+  const int* hcol;    // [n_tiles][K]      col_h of the owned blocks
+  const int* arrow;   // [n_tiles][nGB * K] >= 0: (pose block rows, global block column), < -1: -2 - slot with the pose block as column
+  const int* col_gb;  // [ncol] global block (index into the launch's list) of an accumulator column, and its component
+  const int* col_sc;
+  const int* gb_h;    // [nGB] col_h of the global block
+  int* ranges;        // [n_batches][2][n_tiles + 1]: first observation with segment >= j K - 5, and >= j K
+  const int* gbase;   // [n_batches + 1] first group of every batch in the launch's group array
+  const F1ObsTab* otab;     // per group
+  const F1Lite* lite;       // per group, rewritten by k_obs_common
+};
+
+template <bool EQUI, bool EXPW>
+__global__ __launch_bounds__(256, (EQUI || EXPW) ? MC_RB_OCC : 4) void k_reproj_gram(const ReprojBatchView* __restrict__ views, DevCommon dc,
+                                                      const GroupRec* __restrict__ groups, const F1Pass* __restrict__ passes, int n_passes,
+                                                      const F1Common* __restrict__ common, double* __restrict__ Gbuf, int jpart_base) {
+  enum { ZW = 2 * 64 + 4 };
+  __shared__ double zs_all[4][7 * ZW];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  double* zs = zs_all[wv];
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  const int pi = blockIdx.x * 4 + wv;
+  double Jacc = 0.0;
+  if (pi < n_passes) {
+    const F1Pass pr = passes[pi];
+    const ReprojBatchView b = views[pr.batch];
+    const int term = pr.term_first + lane;
+    bool live = lane < pr.n_terms;
+    int gi = pr.obs_first;
+    if (live) {
+      int o = 0;
+      while (o + 1 < pr.n_obs && term >= groups[pr.obs_first + o + 1].term_first) ++o;
+      gi = pr.obs_first + o;
+    }
+    const F1Common& cm = common[gi];
+    if (live && !cm.ok) live = false;   // k_obs_common has raised the status
+    double2* zp = reinterpret_cast<double2*>(zs + 2 * lane);
+    constexpr int Z2 = ZW / 2;
+    if (live) {
+      double pc[3], Jc[6], e[2], sw;
+      TermOut out;
+      f1_project<EQUI, EXPW>(b, dc.x, cm, term, dc.useM != 0, true, pc, Jc, e, sw, out);
+      Jacc = out.w * out.chi2;
+      dc.chi2[b.term_base_global + term] = out.chi2;
+      if (dc.e) { dc.e[b.row_base + 2 * term] = -e[0]; dc.e[b.row_base + 2 * term + 1] = -e[1]; }
+      const double a0[3] = {-sw * Jc[0], -sw * Jc[1], -sw * Jc[2]}, a1[3] = {-sw * Jc[3], -sw * Jc[4], -sw * Jc[5]};
+      double c0[3], c1[3];
+      v3_cross(a0, pc, c0);
+      v3_cross(a1, pc, c1);
+      zp[0 * Z2] = make_double2(a0[0], a1[0]); zp[1 * Z2] = make_double2(a0[1], a1[1]); zp[2 * Z2] = make_double2(a0[2], a1[2]);
+      zp[3 * Z2] = make_double2(c0[0], c1[0]); zp[4 * Z2] = make_double2(c0[1], c1[1]); zp[5 * Z2] = make_double2(c0[2], c1[2]);
+      zp[6 * Z2] = make_double2(e[0], e[1]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) zp[c * Z2] = make_double2(0.0, 0.0);
+    }
+    wave_sync();
+    // 7 x 7 Gram per observation present in the pass (rows [ra, rb) of the tile); operand layout as in k_reproj_build
+    const int c16 = lane & 15, kr = lane >> 4;
+    for (int oo = 0; oo < pr.n_obs; ++oo) {
+      const GroupRec g = groups[pr.obs_first + oo];
+      const int la = max(g.term_first - pr.term_first, 0), lb = min(g.term_first + g.term_count - pr.term_first, pr.n_terms);
+      const int ra = 2 * la, rb = 2 * lb;
+      if (rb <= ra) continue;
+      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      for (int st = ra >> 2; 4 * st < rb; st += 2) {
+        const int r0 = 4 * st + kr, r1 = r0 + 4;
+        const double v0 = (c16 < 7 && r0 >= ra && r0 < rb) ? zs[c16 * ZW + r0] : 0.0;
+        const double v1 = (c16 < 7 && r1 >= ra && r1 < rb) ? zs[c16 * ZW + r1] : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
+      }
+      // C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
+      double* G = Gbuf + (size_t)(pr.obs_first + oo) * 49;
+      if (c16 < 7) {
+        atomic_add_f64(G + kr * 7 + c16, acc0[0] + acc1[0]);
+        if (kr + 4 < 7) atomic_add_f64(G + (kr + 4) * 7 + c16, acc0[1] + acc1[1]);
+      }
+    }
+  }
+  Jacc = wave_sum(Jacc);
+  if (lane == 0) red[wv] = Jacc;
+  __syncthreads();
+  if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// lane = observation g of the launch: every tile boundary (segment j K - 5 for the first kind, j K for the second) that
+// lies between the segment of the observation before it in its camera's time-sorted list and its own gets this
+// observation's position as "first observation at or past the boundary"; the last observation of a camera also closes
+// the boundaries past its own segment.
+__global__ __launch_bounds__(256) void k_f1_ranges(const GroupRec* __restrict__ groups, int n, F1Asm A) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const int cb = groups[g].batch;
+  const int g0 = A.gbase[cb], g1 = A.gbase[cb + 1];
+  const int pos = g - g0, per = A.n_tiles + 1;
+  const long long seg = A.lite[g].seg;
+  const long long prev = g > g0 ? (long long)A.lite[g - 1].seg : -(1LL << 40);
+  int* r0 = A.ranges + (size_t)(cb * 2 + 0) * per;
+  int* r1 = A.ranges + (size_t)(cb * 2 + 1) * per;
+  // boundaries b with prev < b <= seg: first kind b = j K - 5, second kind b = j K
+  auto ceil_div = [](long long a, long long k) { return a >= 0 ? (a + k - 1) / k : -((-a) / k); };
+  {
+    long long j_lo = ceil_div(prev + 1 + 5, A.K), j_hi = (seg + 5 >= 0) ? (seg + 5) / A.K : -1;
+    if (j_lo < 0) j_lo = 0;
+    if (j_hi > A.n_tiles) j_hi = A.n_tiles;
+    for (long long j = j_lo; j <= j_hi; ++j) r0[j] = pos;
+  }
+  {
+    long long j_lo = ceil_div(prev + 1, A.K), j_hi = seg >= 0 ? seg / A.K : -1;
+    if (j_lo < 0) j_lo = 0;
+    if (j_hi > A.n_tiles) j_hi = A.n_tiles;
+    for (long long j = j_lo; j <= j_hi; ++j) r1[j] = pos;
+  }
+  if (g == g1 - 1) {   // boundaries past the last observation
+    long long j0 = seg + 5 >= 0 ? (seg + 5) / A.K + 1 : 0, j1 = seg >= 0 ? seg / A.K + 1 : 0;
+    for (long long j = j0 < 0 ? 0 : j0; j <= A.n_tiles; ++j) r0[j] = pos + 1;
+    for (long long j = j1 < 0 ? 0 : j1; j <= A.n_tiles; ++j) r1[j] = pos + 1;
+  }
+}
+
+#ifndef MC_ASM_SKIP
+#define MC_ASM_SKIP 0   // diagnostic builds: bit mask of phases left out (results wrong, timing meaningful)
+#endif
+__global__ __launch_bounds__(256) void k_reproj_assemble(DevCommon dc, const GroupRec* __restrict__ groups,
+                                                         const F1Chain* __restrict__ chain, const double* __restrict__ Gbuf, F1Asm A) {
+  extern __shared__ double sm[];
+  // per-wave scratch (doubles): G 49, K 6 x 19, T 7 x 20, M 210, w 6, then the observation's table (54 ints)
+  enum { O_G = 0, O_K = 52, O_T = 168, O_M = 308, O_W = 518, O_TAB = 524, WS = 552 };
+  static_assert(sizeof(F1ObsTab) == 56 * sizeof(int) && O_TAB + 28 <= WS, "wave scratch layout");
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int K = A.K, R = 6 * K, ncol = A.ncol, nGB = A.nGB;
+  double* bandAcc = sm;                    // [R columns][36 rows]: column (k, b), row (5 - d) * 6 + a
+  double* arrowAcc = bandAcc + R * 36;     // [ncol][R]
+  double* rhsAcc = arrowAcc + R * ncol;    // [R]
+  double* ws = rhsAcc + R + wv * WS;
+  int* it = reinterpret_cast<int*>(rhsAcc + R + 4 * WS);
+  int* band_slot = it;           it += R;          // K * 6
+  int* hcol = it;                it += K;
+  int* arrow_slot = it;          it += nGB * K;
+  int* cnt = it;                 it += A.n_batches + 1;
+  int* first = it;
+  const int t = blockIdx.x, c0 = t * K;
+  for (int i = tid; i < R * 36 + R * ncol + R; i += 256) sm[i] = 0.0;
+  for (int i = tid; i < R; i += 256) band_slot[i] = A.band[(size_t)t * R + i];
+  for (int i = tid; i < K; i += 256) hcol[i] = A.hcol[(size_t)t * K + i];
+  for (int i = tid; i < nGB * K; i += 256) arrow_slot[i] = A.arrow[(size_t)t * nGB * K + i];
+  if (tid < A.n_batches) {
+    const int per = A.n_tiles + 1;
+    const int lo = A.ranges[(tid * 2 + 0) * per + t], hi = A.ranges[(tid * 2 + 1) * per + t + 1];
+    first[tid] = lo;
+    cnt[tid + 1] = max(hi - lo, 0);
+  }
+  __syncthreads();
+  if (tid == 0) { cnt[0] = 0; for (int i = 0; i < A.n_batches; ++i) cnt[i + 1] += cnt[i]; }
+  __syncthreads();
+  const int total = cnt[A.n_batches];
+  const F1ObsTab& tab = *reinterpret_cast<const F1ObsTab*>(ws + O_TAB);
+  const double* w = ws + O_W;
+  for (int item = wv; item < total; item += 4) {
+    int cb = 0;
+    while (item >= cnt[cb + 1]) ++cb;
+    const int gi = A.gbase[cb] + first[cb] + (item - cnt[cb]);
+    wave_sync();                               // the previous observation is done with the wave's scratch
+    // everything the observation needs, in one round of independent loads
+    if (lane < 49) ws[O_G + lane] = Gbuf[(size_t)gi * 49 + lane];
+    for (int i = lane; i < 6 * F1_CORE; i += 64) ws[O_K + i] = chain[gi].K[i];
+    if (lane < 28) ws[O_TAB + lane] = reinterpret_cast<const double*>(A.otab + gi)[lane];
+    const F1Lite lt = A.lite[gi];
+    if (lane < S6) ws[O_W + lane] = lt.w[lane];
+    if (!lt.ok) continue;                      // k_obs_common has raised the status
+    const int ls = lt.seg - (c0 - 5);          // local segment: live blocks ls .. ls + 5, owned blocks 5 .. 5 + K - 1
+    if (ls < 0 || ls >= K + 5) continue;       // cannot happen: the ranges come from the same segments
+    wave_sync();
+    if (MC_ASM_SKIP & 16) continue;
+    const double* G = ws + O_G;
+    const double* Ks = ws + O_K;
+    for (int idx = lane; idx < 140; idx += 64) {
+      const int i = idx / 20, c = idx - 20 * i;
+      double v = G[i * 7 + 6];
+      if (c < F1_CORE) {
+        v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v += G[i * 7 + j] * Ks[j * F1_CORE + c];
+      }
+      ws[O_T + idx] = v;
+    }
+    wave_sync();
+    for (int idx = lane; idx < 210; idx += 64) {
+      int bb = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+      while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
+      while (bb * (bb + 1) / 2 > idx) --bb;
+      const int ea = idx - bb * (bb + 1) / 2, eb = bb;
+      double m = ws[O_T + 6 * 20 + eb];
+      if (ea < F1_CORE) {
+        m = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m += Ks[i * F1_CORE + ea] * ws[O_T + i * 20 + eb];
+      }
+      ws[O_M + idx] = m;
+    }
+    wave_sync();
+    const double* M = ws + O_M;               // upper triangle of the 20 x 20 core Gram: (a <= b) at b (b + 1) / 2 + a
+    const int n_glob = tab.n_glob;
+    if (tab.has_coef && !(MC_ASM_SKIP & 1)) {
+      // band: block pair (i <= j) of the live coefficients, entry (a, b) = w_i w_j M(a, b); owner of block column ls + j
+      for (int idx = lane; idx < 21 * 36; idx += 64) {
+        const int p = idx / 36, e = idx - 36 * p, a = e / 6, bq = e - 6 * a;
+        const int j = p >= 15 ? 5 : p >= 10 ? 4 : p >= 6 ? 3 : p >= 3 ? 2 : p >= 1 ? 1 : 0;
+        const int i = p - (j * (j + 1)) / 2, d = j - i;
+        const int k = ls + j - 5;
+        if (k < 0 || k >= K || (d == 0 && a > bq)) continue;
+        const int lo = min(a, bq), hi = max(a, bq);
+        const double v = w[i] * w[j] * M[(hi * (hi + 1)) / 2 + lo];
+        if (v != 0.0) atomicAdd(&bandAcc[(k * 6 + bq) * 36 + (5 - d) * 6 + a], v);
+      }
+      // coefficient rows x global columns, and the coefficient part of rhs (core column 19 = residual)
+      for (int idx = lane; idx < ((MC_ASM_SKIP & 2) ? 0 : 36 * (n_glob + 1)); idx += 64) {
+        const int gq = idx / 36, e = idx - 36 * gq, i = e / 6, a = e - 6 * i;
+        const int k = ls + i - 5;
+        if (k < 0 || k >= K) continue;
+        const int kc = gq < n_glob ? tab.gk[gq] : 19;
+        const double v = w[i] * M[(kc * (kc + 1)) / 2 + a];
+        if (v == 0.0) continue;
+        if (gq < n_glob) atomicAdd(&arrowAcc[tab.acol[gq] * R + k * 6 + a], v);
+        else atomicAdd(&rhsAcc[k * 6 + a], -v);
+      }
+    }
+    // entries between two global design variables and their part of rhs: once per observation, from its primary owner
+    if (ls >= 5 && !(MC_ASM_SKIP & 4)) {
+      const FpView f = fp_view_at(dc.fp_data + dc.fp_off[groups[gi].fp]);   // read only where a pair has no replica
+      f1_flush(f, dc, M, w, -1, 0, tab.glc, tab.gk, tab.ggc, n_glob, n_glob, false, lane, 64);
+    }
+  }
+  __syncthreads();
+  if (MC_ASM_SKIP & 8) return;
+  // ---- the owner's stores: plain read-modify-write, one pass over what it accumulated
+  for (int idx = tid; idx < R * 36; idx += 256) {
+    const double v = bandAcc[idx];
+    if (v == 0.0) continue;
+    const int col = idx / 36, e = idx - 36 * col, k = col / 6, bq = col - 6 * k, d = 5 - e / 6, a = e % 6;
+    const int slot = band_slot[k * 6 + d];
+    if (slot < 0) continue;
+    dc.Cx[slot + bq * hcol[k] + (bq * (bq + 1)) / 2 + a] += v;
+  }
+  for (int idx = tid; idx < ncol * R; idx += 256) {
+    const double v = arrowAcc[idx];
+    if (v == 0.0) continue;
+    const int gc = idx / R, row = idx - gc * R, k = row / 6, a = row - 6 * k;
+    const int gb = A.col_gb[gc], sc = A.col_sc[gc];
+    const int enc = arrow_slot[gb * K + k];
+    if (enc >= 0) dc.Cx[enc + sc * A.gb_h[gb] + (sc * (sc + 1)) / 2 + a] += v;                  // column = global design variable
+    else if (enc < -1) dc.Cx[(-2 - enc) + sc + a * hcol[k] + (a * (a + 1)) / 2] += v;          // column = coefficient
+  }
+  for (int idx = tid; idx < R; idx += 256) {
+    const double v = rhsAcc[idx];
+    if (v != 0.0) dc.rhs[A.pose_col0 + c0 * 6 + idx] += v;
+  }
 }
 
 __device__ __forceinline__ int b_pose_first_block(const LidarBatchView& b) { return b.sp.first_block; }
@@ -1621,7 +1935,9 @@ __global__ __launch_bounds__(128) void k_jt_stream(const StreamBatch<View>* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// BSplineMotionError (BSplineMotionError.hpp:62-77, 93-166): one lane per spline coefficient.
+// BSplineMotionError (BSplineMotionError.hpp:62-77, 93-166): one lane per (spline coefficient i, band offset d) -- the
+// block Q(i, i - d) and its mirror image Q(i + d, i)^T.  (One lane per coefficient walked 6 blocks x 36 dependent atomics:
+// 63 us for 12 000 coefficients on 47 workgroups.)
 struct MotionView {
   const double* Qband;   // n_coeff x S x (D x D), Q(i, i - d) row-major
   const int* slot;       // n_coeff x S: value offset of block (i-d, i) or -1
@@ -1631,31 +1947,29 @@ struct MotionView {
 };
 __global__ __launch_bounds__(256) void k_motion(const MotionView* __restrict__ views, DevCommon dc, int jpart_base) {
   const MotionView m = views[blockIdx.y];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int D = m.D, S = m.S;
+  const int i = id / S, d = id - i * S;
   double part = 0.0;
   if (i < m.n_coeff) {
     const double* c = dc.x + m.param_off;
     double qc[6] = {0, 0, 0, 0, 0, 0};
-    for (int d = 0; d < S; ++d) {
-      int j = i - d;
-      if (j >= 0) {  // Q(i, j)
-        const double* Q = m.Qband + ((size_t)i * S + d) * D * D;
-        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) qc[r] += Q[r * D + cc] * c[j * D + cc];
-      }
-      int jj = i + d;
-      if (d > 0 && jj < m.n_coeff) {  // Q(i, jj) = Q(jj, i)^T
-        const double* Q = m.Qband + ((size_t)jj * S + d) * D * D;
-        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) qc[r] += Q[cc * D + r] * c[jj * D + cc];
-      }
+    const int j = i - d, jj = i + d;
+    if (j >= 0) {  // Q(i, j)
+      const double* Q = m.Qband + ((size_t)i * S + d) * D * D;
+      for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) qc[r] += Q[r * D + cc] * c[j * D + cc];
+    }
+    if (d > 0 && jj < m.n_coeff) {  // Q(i, jj) = Q(jj, i)^T
+      const double* Q = m.Qband + ((size_t)jj * S + d) * D * D;
+      for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) qc[r] += Q[cc * D + r] * c[jj * D + cc];
     }
     for (int r = 0; r < D; ++r) part += c[i * D + r] * qc[r];
     if (dc.build && m.first_block >= 0) {
-      int h = dc.col_h[m.first_block + i];
-      for (int r = 0; r < D; ++r) atomic_add_f64(dc.rhs + m.first_col + i * D + r, -qc[r]);
-      for (int d = 0; d < S && i - d >= 0; ++d) {
+      for (int r = 0; r < D; ++r) if (qc[r] != 0.0) atomic_add_f64(dc.rhs + m.first_col + i * D + r, -qc[r]);
+      if (j >= 0) {
+        const int h = dc.col_h[m.first_block + i];
         const double* Q = m.Qband + ((size_t)i * S + d) * D * D;
-        int base = m.slot[i * S + d];
+        const int base = m.slot[i * S + d];
         for (int cc = 0; cc < D; ++cc)
           for (int r = 0; r < (d == 0 ? cc + 1 : D); ++r)
             atomic_add_f64(dc.Cx + base + cc * h + (cc * (cc + 1)) / 2 + r, Q[r * D + cc]);
@@ -1671,7 +1985,7 @@ __global__ __launch_bounds__(256) void k_motion(const MotionView* __restrict__ v
     double s = red[0] + red[1] + red[2] + red[3];
     dc.Jpart[jpart_base + blockIdx.y * gridDim.x + blockIdx.x] = s;
   }
-  if (i == 0) { if (dc.e) dc.e[m.row] = 0.0; }
+  if (id == 0) { if (dc.e) dc.e[m.row] = 0.0; }
 }
 // chi^2 of a motion term = sum of its partials (raw squared error, BSplineMotionError.hpp:76)
 __global__ void k_motion_chi2(const MotionView* __restrict__ views, const double* Jpart, int base, int n, double* chi2) {
@@ -1856,6 +2170,15 @@ struct LaunchUnit {
   int max_gs = 0, max_nbc = 0;                     // IMU launches: stored other columns / bias coefficients per chunk, at most
   DevBuf<ImageRec> images;   // F1: runs of observations of one camera at one time; F2: runs of observations of one camera
   int n_images = 0;
+  // F1, split build path (k_reproj_gram / k_f1_ranges / k_reproj_assemble); f1_split = false keeps k_reproj_build_img
+  bool f1_split = false;
+  int n_passes = 0, f1_lds = 0;
+  DevBuf<F1Pass> passes;
+  DevBuf<double> Gbuf;       // per observation: 7 x 7 Gram of [a, a x p_c | residual]
+  DevBuf<F1ObsTab> otab;
+  DevBuf<F1Lite> lite;
+  DevBuf<int> f1_band, f1_hcol, f1_arrow, f1_col_gb, f1_col_sc, f1_gb_h, f1_ranges, f1_gbase;
+  F1Asm f1asm{};
   int static_ld = 0;         // F2: row stride of the LDS tile
 };
 
@@ -1952,6 +2275,12 @@ struct mc_context {
   }
 
   void uploadStructure();
+  void setupF1Split(const std::vector<GroupRec>& groups);
+  void launchF1Assemble(const DevCommon& dc, hipStream_t st) {
+    LaunchUnit& L = lu[LAUNCH_REPROJ];
+    hipLaunchKernelGGL(k_reproj_assemble, dim3(L.f1asm.n_tiles), dim3(256), L.f1_lds, st, dc, L.groups.p, L.chain.p, L.Gbuf.p, L.f1asm);
+    HIP_CHECK(hipGetLastError());
+  }
   // rep_buf: replica buffer to use instead of the context's own (the allocation-free entry point passes the per-device
   // scratch array); serial: keep every launch on the caller's stream (no side streams are created or used)
   void launchAll(int build, int useM, double* dCx, double* dRhs, double* dJ, double* dE, hipStream_t st,
@@ -1997,6 +2326,162 @@ void batchCounts(const Problem& P, const Batch& b, double& fd, double& fl, doubl
     fd = fl = 2.0 * sp.n_coeff * (2 * sp.order - 1) * sp.dim * sp.dim;
   }
   rec = recb[b.kind] * b.n_terms;
+}
+
+// Tables of the split F1 build path (see k_reproj_assemble): corner passes, the global design variables the observations
+// touch and their accumulator columns, and per owner tile the value offsets of its band blocks and of its rows in the global
+// columns.  Leaves f1_split = false (k_reproj_build_img stays) when the problem does not have the shape the path assumes.
+void mc_context::setupF1Split(const std::vector<GroupRec>& groups) {
+  LaunchUnit& L = lu[LAUNCH_REPROJ];
+  L.f1_split = false;
+  {   // default while the assembly kernel is being tuned: off (MC_F1_SPLIT=1 turns it on)
+    const char* e = std::getenv("MC_F1_SPLIT");
+    if (!e || e[0] != '1') return;
+  }
+  if (groups.empty() || P.world > 1) return;   // shards keep the per-image kernel (its writers are what finalize() marked)
+  // one active pose spline behind every batch, observations of a batch in time order, corners contiguous
+  std::vector<const Batch*> rb;
+  for (const Batch& b : P.batches) if (b.kind == KIND_REPROJ) rb.push_back(&b);
+  const int spline = rb[0]->spline;
+  for (const Batch* b : rb) if (b->spline != spline) return;
+  const SplineRec& sp = P.splines[spline];
+  const int block0 = P.dvs[sp.first_dv].block;
+  if (block0 < 0) return;
+  std::vector<int> gbase(rb.size() + 1, 0);
+  {
+    size_t g = 0;
+    for (size_t k = 0; k < rb.size(); ++k) {
+      gbase[k] = (int)g;
+      double last = -INFINITY;
+      int next_term = -1;
+      while (g < groups.size() && groups[g].batch == (int)k) {
+        const double tg = rb[k]->t[groups[g].aux];
+        if (tg < last) return;
+        last = tg;
+        if (next_term >= 0 && groups[g].term_first != next_term) return;
+        next_term = groups[g].term_first + groups[g].term_count;
+        ++g;
+      }
+    }
+    gbase[rb.size()] = (int)g;
+    if (g != groups.size()) return;
+  }
+  // corner passes: 64 consecutive corners of one batch
+  std::vector<F1Pass> passes;
+  for (size_t k = 0; k < rb.size(); ++k) {
+    int g = gbase[k];
+    const int gend = gbase[k + 1];
+    if (g == gend) continue;
+    int term = groups[g].term_first;
+    const int term_end = groups[gend - 1].term_first + groups[gend - 1].term_count;
+    while (term < term_end) {
+      while (groups[g].term_first + groups[g].term_count <= term) ++g;
+      const int n = std::min(64, term_end - term);
+      int g2 = g;
+      while (g2 + 1 < gend && groups[g2 + 1].term_first < term + n) ++g2;
+      passes.push_back(F1Pass{(int)k, term, n, g, g2 - g + 1});
+      term += n;
+    }
+  }
+  // global design variables of the observations -> accumulator columns
+  std::map<int, int> gb_index;      // block -> position in the list
+  std::vector<int> gb_block, gb_col0;
+  int ncol = 0;
+  auto gbOf = [&](int dv) {
+    if (dv < 0 || P.dvs[dv].block < 0) return -1;
+    const int blk = P.dvs[dv].block;
+    auto it = gb_index.find(blk);
+    if (it != gb_index.end()) return it->second;
+    const int id = (int)gb_block.size();
+    gb_index.emplace(blk, id);
+    gb_block.push_back(blk);
+    gb_col0.push_back(ncol);
+    ncol += P.block_dim[blk];
+    return id;
+  };
+  const bool with_rep = rep_stride > 0;
+  std::vector<F1ObsTab> otab(groups.size());
+  for (size_t g = 0; g < groups.size(); ++g) {
+    const Batch& b = *rb[groups[g].batch];
+    const int u = groups[g].aux;
+    const int dv[5] = {b.dv[0], b.dv[1], b.obs_dv_q[u], b.obs_dv_t[u], b.dv[2]};
+    static const int want[5] = {3, 3, 3, 3, 1}, role[5] = {F1_ROLE_QCB, F1_ROLE_TCB, F1_ROLE_QPW, F1_ROLE_TPW, F1_ROLE_TOFF}, core[5] = {6, 9, 12, 15, 18};
+    F1ObsTab& tb = otab[g];
+    std::memset(&tb, 0, sizeof tb);
+    const int* fp = &P.fp_data[P.fp_off[groups[g].fp]];
+    tb.has_coef = fp[4 + F1_ROLE_COEF] >= 0 ? 1 : 0;
+    for (int r = 0; r < 5; ++r) {
+      const int id = gbOf(dv[r]);
+      if (id < 0) continue;
+      if (P.block_dim[gb_block[id]] != want[r] || fp[4 + role[r]] < 0) return;
+      for (int d = 0; d < want[r]; ++d) {
+        const int at = tb.n_glob++;
+        tb.glc[at] = fp[4 + role[r]] + d;
+        tb.gk[at] = core[r] + d;
+        tb.ggc[at] = (with_rep && P.gcb[gb_block[id]] >= 0) ? P.gcb[gb_block[id]] + d : -1;
+        tb.acol[at] = gb_col0[id] + d;
+      }
+    }
+  }
+  const int nGB = (int)gb_block.size();
+  std::vector<int> col_gb(std::max(ncol, 1), 0), col_sc(std::max(ncol, 1), 0), gb_h(std::max(nGB, 1), 0);
+  for (int i = 0; i < nGB; ++i) {
+    gb_h[i] = P.col_h[gb_block[i]];
+    for (int c = 0; c < P.block_dim[gb_block[i]]; ++c) { col_gb[gb_col0[i] + c] = i; col_sc[gb_col0[i] + c] = c; }
+  }
+  // tile size: the largest whose accumulators leave three workgroups per CU
+  int K = 0, lds = 0;
+  const int forced = std::getenv("MC_F1_TILE") ? atoi(std::getenv("MC_F1_TILE")) : 0;
+  for (int cand : {16, 8, 4, 2}) {
+    if (forced > 0 && cand != forced) continue;
+    const int R = 6 * cand;
+    const size_t doubles = (size_t)R * 36 + (size_t)R * ncol + R + 4 * 552;
+    const size_t ints = (size_t)R + cand + (size_t)nGB * cand + 2 * rb.size() + 1;
+    const size_t bytes = doubles * sizeof(double) + ints * sizeof(int) + 16;
+    if (bytes <= 53 * 1024 || (forced > 0 && bytes <= 150 * 1024)) { K = cand; lds = (int)bytes; break; }
+  }
+  if (K == 0) return;
+  const int n_tiles = (sp.n_coeff + K - 1) / K;
+  auto lookup = [&](int rb_, int cb_) {
+    const std::vector<int>& rows = P.col_rows[cb_];
+    auto it = std::lower_bound(rows.begin(), rows.end(), rb_);
+    return (it != rows.end() && *it == rb_) ? P.Cp[P.block_col[cb_]] + P.col_roff[cb_][it - rows.begin()] : -1;
+  };
+  std::vector<int> band((size_t)n_tiles * K * 6, -1), hcol((size_t)n_tiles * K, 0), arrow((size_t)n_tiles * std::max(nGB, 1) * K, -1);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int k = 0; k < K; ++k) {
+      const int c = t * K + k;
+      if (c >= sp.n_coeff) continue;
+      const int pb = block0 + c;
+      hcol[(size_t)t * K + k] = P.col_h[pb];
+      for (int d = 0; d < 6 && c - d >= 0; ++d) band[((size_t)t * K + k) * 6 + d] = lookup(pb - d, pb);
+      for (int i = 0; i < nGB; ++i) {
+        const int gblk = gb_block[i];
+        int enc = -1;
+        if (gblk > pb) enc = lookup(pb, gblk);
+        else { const int s = lookup(gblk, pb); enc = s >= 0 ? -2 - s : -1; }
+        arrow[((size_t)t * nGB + i) * K + k] = enc;
+      }
+    }
+  L.passes.upload(passes);
+  L.n_passes = (int)passes.size();
+  L.Gbuf.alloc(groups.size() * 49);
+  L.otab.upload(otab);
+  L.lite.alloc(groups.size());
+  L.f1_band.upload(band); L.f1_hcol.upload(hcol); L.f1_arrow.upload(arrow);
+  L.f1_col_gb.upload(col_gb); L.f1_col_sc.upload(col_sc); L.f1_gb_h.upload(gb_h);
+  L.f1_ranges.alloc(rb.size() * 2 * (size_t)(n_tiles + 1));
+  L.f1_gbase.upload(gbase);
+  F1Asm& A = L.f1asm;
+  A.K = K; A.n_tiles = n_tiles; A.ncol = ncol; A.nGB = nGB; A.n_batches = (int)rb.size();
+  A.pose_block0 = block0; A.pose_col0 = P.dvs[sp.first_dv].col;
+  A.band = L.f1_band.p; A.hcol = L.f1_hcol.p; A.arrow = L.f1_arrow.p;
+  A.col_gb = L.f1_col_gb.p; A.col_sc = L.f1_col_sc.p; A.gb_h = L.f1_gb_h.p;
+  A.ranges = L.f1_ranges.p; A.gbase = L.f1_gbase.p; A.otab = L.otab.p; A.lite = L.lite.p;
+  L.f1_lds = lds;
+  if (lds > 64 * 1024)
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_reproj_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  L.f1_split = true;
 }
 
 void mc_context::uploadStructure() {
@@ -2218,7 +2703,7 @@ void mc_context::uploadStructure() {
       v.param_off = s.param_off; v.first_block = b0; v.first_col = b0 >= 0 ? P.dvs[s.first_dv].col : -1;
       v.row = b.row_base; v.term = term_base;
       mviews.push_back(v);
-      L.motion_blocks = std::max(L.motion_blocks, (s.n_coeff + 255) / 256);
+      L.motion_blocks = std::max(L.motion_blocks, (s.n_coeff * s.order + 255) / 256);   // a lane per (coefficient, band offset)
     }
     term_base += b.n_terms;
     db.push_back(std::move(d));
@@ -2266,6 +2751,8 @@ void mc_context::uploadStructure() {
         L.images.upload(images);
         L.n_images = (int)images.size();
         L.n_jpart = L.n_images;
+        setupF1Split(groups[l]);
+        if (L.f1_split) L.n_jpart = std::max(L.n_jpart, (L.n_passes + 3) / 4);
       } else if (l == LAUNCH_STATIC) {
         L.common2.alloc(groups[l].size());
         L.images.upload(static_runs);
@@ -2315,6 +2802,8 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     if (use_rep) HIP_CHECK(hipMemsetAsync(rep_base, 0, sizeof(double) * (size_t)Problem::REP_COPIES * (rep_stride + P.rep_cols), st));
   }
   if (dE && P.world > 1) HIP_CHECK(hipMemsetAsync(dE, 0, sizeof(double) * P.j_rows, st));
+  // cost partials: the evaluate and the build kernels of a family may use different numbers of workgroups
+  HIP_CHECK(hipMemsetAsync(Jpart.p, 0, sizeof(double) * std::max(1, n_jpart), st));
   // per-launch timing (ev) needs the launches back to back on one stream
   static const int side_of[N_LAUNCH] = {-1, -1, 0, 1, 2, 0, -1, -1};   // reprojection kernels stay on the caller's stream
   const hipStream_t caller = st;
@@ -2339,6 +2828,20 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
     }
     switch (l) {
       case LAUNCH_REPROJ:
+        if (build && L.f1_split) {
+          // evaluation (lane = corner, 7 x 7 Grams per observation) now, assembly by owner tiles once the other families'
+          // kernels have joined: its stores are plain read-modify-writes
+          hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
+                             L.chain.p, fp_data.p, fp_off.p, status.p, L.lite.p);
+          HIP_CHECK(hipMemsetAsync(L.Gbuf.p, 0, sizeof(double) * L.Gbuf.n, st));
+          hipLaunchKernelGGL(k_f1_ranges, dim3((L.n_items + 255) / 256), dim3(256), 0, st, L.groups.p, L.n_items, L.f1asm);
+          auto kg = L.reproj_equi ? (L.reproj_expw ? k_reproj_gram<true, true> : k_reproj_gram<true, false>)
+                                  : (L.reproj_expw ? k_reproj_gram<false, true> : k_reproj_gram<false, false>);
+          hipLaunchKernelGGL(kg, dim3((L.n_passes + 3) / 4), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.passes.p, L.n_passes, L.common.p,
+                             L.Gbuf.p, L.jpart_base);
+          if (!fork) launchF1Assemble(dc, st);   // serial launches: nothing else is in flight
+          break;
+        }
         hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
                            build ? L.chain.p : nullptr);
         if (build) {
@@ -2396,6 +2899,7 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   }
   st = caller;
   joinSides();
+  if (fork && build && lu[LAUNCH_REPROJ].f1_split && lu[LAUNCH_REPROJ].n_items) launchF1Assemble(dc, st);
   if (ev) HIP_CHECK(hipEventRecord((*ev)[N_LAUNCH], st));
   if (use_rep) {
     const int n = (int)P.rep_idx.size();
