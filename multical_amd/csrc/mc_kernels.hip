@@ -804,6 +804,102 @@ __global__ __launch_bounds__(256, (EQUI || EXPW) ? MC_RB_OCC : 4) void k_reproj_
   if (tid == 0) dc.Jpart[jpart_base + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Expansion behind k_reproj_gram, atomic form: a WAVE per image (the observations of one camera at one time), no workgroup
+// barrier, 7.6 KB of LDS per wave -- five workgroups per CU, so the dependent loads of an observation's record (G, chain
+// matrix, footprint) of one wave hide behind the others'.  Per observation M = Kt^T G Kt; the part that does not involve the
+// board pose is summed over the image's observations in the wave's LDS and flushed once per image, the board rows /
+// columns per observation -- the same entries, the same fp64 atomics and replicas as k_reproj_build_img's phases 3 and 4.
+__global__ __launch_bounds__(256) void k_reproj_expand(DevCommon dc, const GroupRec* __restrict__ groups, const ImageRec* __restrict__ images,
+                                                       int n_images, const F1Lite* __restrict__ lite, const F1Chain* __restrict__ chain,
+                                                       const double* __restrict__ Gbuf) {
+  enum { FPW = 384, O_G = 0, O_K = 52, O_T = 168, O_M = 308, O_MI = 520, O_W = 732, O_FP = 738, O_GL = O_FP + FPW / 2, WS = O_GL + 20 };
+  __shared__ double ws_all[4][WS];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int imi = blockIdx.x * 4 + wv;
+  if (imi >= n_images) return;   // no workgroup barrier below
+  double* ws = ws_all[wv];
+  int* fpl = reinterpret_cast<int*>(ws + O_FP);
+  int* glc = reinterpret_cast<int*>(ws + O_GL); int* gk = glc + 13; int* ggc = gk + 13;
+  const ImageRec im = images[imi];
+  for (int i = lane; i < 210; i += 64) ws[O_MI + i] = 0.0;
+  int l_rc0 = -1, l_shift = 0, l_nnb = 0, l_fp_begin = 0;
+  bool any = false, l_staged = false;
+  for (int o = 0; o < im.count; ++o) {
+    const int gi = im.first + o;
+    const F1Lite lt = lite[gi];
+    if (!lt.ok) continue;                      // k_obs_common has raised the status
+    const GroupRec gr = groups[gi];
+    const int fp_begin = dc.fp_off[gr.fp], fp_len = dc.fp_off[gr.fp + 1] - fp_begin;
+    const bool fp_staged = fp_len <= FPW;
+    wave_sync();                               // the previous observation's flush is done with the scratch
+    if (lane < 49) ws[O_G + lane] = Gbuf[(size_t)gi * 49 + lane];
+    for (int i = lane; i < 6 * F1_CORE; i += 64) ws[O_K + i] = chain[gi].K[i];
+    if (lane < S6) ws[O_W + lane] = lt.w[lane];
+    if (fp_staged) for (int i = lane; i < fp_len; i += 64) fpl[i] = dc.fp_data[fp_begin + i];
+    wave_sync();
+    FpView f = fp_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + fp_begin);
+    const int rc0 = f.rolecol[F1_ROLE_COEF];
+    const int coef_shift = rc0 >= 0 ? lt.seg - f.coef_lo : 0;
+    // global live columns, non-board first: q_c_b (core 6..8), t_c_b (9..11), time offset (18), then q_p_w (12..14), t_p_w (15..17)
+    const int a_qcb = f.rolecol[F1_ROLE_QCB] >= 0, a_tcb = f.rolecol[F1_ROLE_TCB] >= 0, a_toff = f.rolecol[F1_ROLE_TOFF] >= 0;
+    const int a_qpw = f.rolecol[F1_ROLE_QPW] >= 0, a_tpw = f.rolecol[F1_ROLE_TPW] >= 0;
+    const int n_nb = 3 * a_qcb + 3 * a_tcb + a_toff;
+    const int n_glob = n_nb + 3 * a_qpw + 3 * a_tpw;
+    if (lane < 13) {
+      int role, d, pos, kcore;
+      if (lane < 3) { role = F1_ROLE_QCB; d = lane; pos = 0; kcore = 6 + d; }
+      else if (lane < 6) { role = F1_ROLE_TCB; d = lane - 3; pos = 3 * a_qcb; kcore = 9 + d; }
+      else if (lane == 6) { role = F1_ROLE_TOFF; d = 0; pos = 3 * a_qcb + 3 * a_tcb; kcore = 18; }
+      else if (lane < 10) { role = F1_ROLE_QPW; d = lane - 7; pos = n_nb; kcore = 12 + d; }
+      else { role = F1_ROLE_TPW; d = lane - 10; pos = n_nb + 3 * a_qpw; kcore = 15 + d; }
+      const int rc = f.rolecol[role];
+      if (rc >= 0) {
+        glc[pos + d] = rc + d; gk[pos + d] = kcore;
+        const int g = dc.rep ? dc.gcb[f.blocks[4 * f.colblk[rc]]] : -1;
+        ggc[pos + d] = g >= 0 ? g + d : -1;
+      }
+    }
+    const double* G = ws + O_G;
+    const double* Ks = ws + O_K;
+    for (int idx = lane; idx < 140; idx += 64) {
+      const int i = idx / 20, c = idx - 20 * i;
+      double v = G[i * 7 + 6];
+      if (c < F1_CORE) {
+        v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v += G[i * 7 + j] * Ks[j * F1_CORE + c];
+      }
+      ws[O_T + idx] = v;
+    }
+    wave_sync();
+    for (int idx = lane; idx < 210; idx += 64) {
+      int bb = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+      while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
+      while (bb * (bb + 1) / 2 > idx) --bb;
+      const int ea = idx - bb * (bb + 1) / 2, eb = bb;
+      double m = ws[O_T + 6 * 20 + eb];
+      if (ea < F1_CORE) {
+        m = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m += Ks[i * F1_CORE + ea] * ws[O_T + i * 20 + eb];
+      }
+      ws[O_M + idx] = m;
+      const bool board_entry = (ea >= 12 && ea <= 17) || (eb >= 12 && eb <= 17);
+      if (!board_entry) ws[O_MI + idx] += m;     // the wave owns the image: plain add
+    }
+    wave_sync();
+    // board rows / columns of this observation
+    f1_flush(f, dc, ws + O_M, ws + O_W, rc0, coef_shift, glc, gk, ggc, n_nb, n_glob, true, lane, 64);
+    any = true; l_rc0 = rc0; l_shift = coef_shift; l_nnb = n_nb; l_staged = fp_staged; l_fp_begin = fp_begin;
+  }
+  if (!any) return;
+  wave_sync();
+  // image-level part through the last observation's tables, still in place (same camera, same time: same coefficient
+  // buffer, extrinsics and time-offset blocks)
+  FpView f = l_staged ? fp_view_at(fpl) : fp_view_at(dc.fp_data + l_fp_begin);
+  f1_flush(f, dc, ws + O_MI, ws + O_W, l_rc0, l_shift, glc, gk, ggc, l_nnb, l_nnb, false, lane, 64);
+}
+
 // lane = observation g of the launch: every tile boundary (segment j K - 5 for the first kind, j K for the second) that
 // lies between the segment of the observation before it in its camera's time-sorted list and its own gets this
 // observation's position as "first observation at or past the boundary"; the last observation of a camera also closes
@@ -2172,6 +2268,7 @@ struct LaunchUnit {
   int n_images = 0;
   // F1, split build path (k_reproj_gram / k_f1_ranges / k_reproj_assemble); f1_split = false keeps k_reproj_build_img
   bool f1_split = false;
+  bool f1_owner = false;     // assembly by owner tiles (k_reproj_assemble, MC_F1_ASSEMBLE=1) instead of k_reproj_expand
   int n_passes = 0, f1_lds = 0;
   DevBuf<F1Pass> passes;
   DevBuf<double> Gbuf;       // per observation: 7 x 7 Gram of [a, a x p_c | residual]
@@ -2481,6 +2578,7 @@ void mc_context::setupF1Split(const std::vector<GroupRec>& groups) {
   L.f1_lds = lds;
   if (lds > 64 * 1024)
     HIP_CHECK(hipFuncSetAttribute((const void*)k_reproj_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  L.f1_owner = std::getenv("MC_F1_ASSEMBLE") != nullptr;
   L.f1_split = true;
 }
 
@@ -2834,12 +2932,16 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
           hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
                              L.chain.p, fp_data.p, fp_off.p, status.p, L.lite.p);
           HIP_CHECK(hipMemsetAsync(L.Gbuf.p, 0, sizeof(double) * L.Gbuf.n, st));
-          hipLaunchKernelGGL(k_f1_ranges, dim3((L.n_items + 255) / 256), dim3(256), 0, st, L.groups.p, L.n_items, L.f1asm);
+          if (L.f1_owner) hipLaunchKernelGGL(k_f1_ranges, dim3((L.n_items + 255) / 256), dim3(256), 0, st, L.groups.p, L.n_items, L.f1asm);
           auto kg = L.reproj_equi ? (L.reproj_expw ? k_reproj_gram<true, true> : k_reproj_gram<true, false>)
                                   : (L.reproj_expw ? k_reproj_gram<false, true> : k_reproj_gram<false, false>);
           hipLaunchKernelGGL(kg, dim3((L.n_passes + 3) / 4), dim3(256), 0, st, L.rviews.p, dc, L.groups.p, L.passes.p, L.n_passes, L.common.p,
                              L.Gbuf.p, L.jpart_base);
-          if (!fork) launchF1Assemble(dc, st);   // serial launches: nothing else is in flight
+          if (!L.f1_owner) {
+            // expansion with atomics: may overlap the other families' kernels
+            hipLaunchKernelGGL(k_reproj_expand, dim3((L.n_images + 3) / 4), dim3(256), 0, st, dc, L.groups.p, L.images.p, L.n_images, L.lite.p,
+                               L.chain.p, L.Gbuf.p);
+          } else if (!fork) launchF1Assemble(dc, st);   // serial launches: nothing else is in flight
           break;
         }
         hipLaunchKernelGGL(k_obs_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.rviews.p, x.p, L.groups.p, L.n_items, L.common.p,
@@ -2899,7 +3001,7 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
   }
   st = caller;
   joinSides();
-  if (fork && build && lu[LAUNCH_REPROJ].f1_split && lu[LAUNCH_REPROJ].n_items) launchF1Assemble(dc, st);
+  if (fork && build && lu[LAUNCH_REPROJ].f1_split && lu[LAUNCH_REPROJ].f1_owner && lu[LAUNCH_REPROJ].n_items) launchF1Assemble(dc, st);
   if (ev) HIP_CHECK(hipEventRecord((*ev)[N_LAUNCH], st));
   if (use_rep) {
     const int n = (int)P.rep_idx.size();
