@@ -352,6 +352,19 @@ void mc_optimizer_options_default(mc_optimizer_options* o);
  * iterates, same stopping rule, same counters -- on the problem held by ctx; the state in ctx is the result
  * (mc_get_dv_params).  Returns 0, or -1 with the message in mc_host_last_error(). */
 int mc_optimize(mc_context* ctx, const mc_optimizer_options* options, mc_solution_return_value* out);
+/* The same loop over time-window shards (mc_set_shard: one process per GPU, every context holds its window's terms, the
+ * state is replicated): Optimizer2::optimize (Optimizer2.cpp:183-275) with applyStateUpdate / revertLastStateUpdate
+ * (:292-320) applied by every rank to its replica.  The caller supplies the two collectives: `allreduce` sums n doubles of
+ * DEVICE memory over the ranks in place (RCCL; the Python binding passes torch.distributed.all_reduce), `broadcast`
+ * sends n doubles of HOST memory from rank `root` to all; both return 0 on success and are called in the same order on
+ * every rank.  Per trial step the cost (1 double) is summed; the partial value array and gradient are summed only when a
+ * trial's linearisation is adopted; rank 0 factorises and solves, the step is broadcast, every rank applies it.  Same
+ * accepted / rejected sequence and estimates as mc_optimize on the unsharded problem (tests/test_sharding_gloo.py).  With
+ * world == 1 the callbacks are not used and may be NULL. */
+typedef int (*mc_allreduce_sum_fn)(void* user, double* device_buf, long long n);
+typedef int (*mc_broadcast_fn)(void* user, double* host_buf, long long n, int root);
+int mc_optimize_sharded(mc_context* ctx, const mc_optimizer_options* options, mc_solution_return_value* out,
+                        mc_allreduce_sum_fn allreduce, mc_broadcast_fn broadcast, void* user);
 const char* mc_host_last_error(void);
 
 #ifdef __cplusplus

@@ -116,6 +116,11 @@ SIGNATURES.update({
     "mc_host_last_error": (C.c_char_p, []),
 })
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong)
+BROADCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int)
+SIGNATURES["mc_optimize_sharded"] = (C.c_int, [_ctx, C.POINTER(OptimizerOptions), C.POINTER(SolutionReturnValue), ALLREDUCE_FN,
+                                               BROADCAST_FN, C.c_void_p])
+
 _lib = None
 
 

@@ -221,6 +221,43 @@ class HipApi(object):
         self.finalized = True
         return {f: getattr(r, f) for f, _ in r._fields_}
 
+    def optimize_sharded(self, allreduce, broadcast, **kw):
+        """mc_optimize_sharded: Optimizer2::optimize over time-window shards (this context was given set_shard(rank, world)).
+        allreduce(ptr, n): sum n doubles of DEVICE memory at address ptr over the ranks, in place; broadcast(ptr, n, root): n
+        doubles of HOST memory from rank root to all.  torch_collectives() makes both from torch.distributed."""
+        o = _lib.OptimizerOptions()
+        self.lib.mc_optimizer_options_default(C.byref(o))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown option %s" % k)
+            setattr(o, k, v)
+        failure = []
+
+        def _ar(user, ptr, n):
+            try:
+                allreduce(ptr, n)
+                return 0
+            except Exception as ex:   # an exception must not unwind through the C frames
+                failure.append(ex)
+                return -1
+
+        def _bc(user, ptr, n, root):
+            try:
+                broadcast(ptr, n, root)
+                return 0
+            except Exception as ex:
+                failure.append(ex)
+                return -1
+        ar, bc = _lib.ALLREDUCE_FN(_ar), _lib.BROADCAST_FN(_bc)
+        r = _lib.SolutionReturnValue()
+        rc = self.lib.mc_optimize_sharded(self.ctx, C.byref(o), C.byref(r), ar, bc, None)
+        if failure:
+            raise failure[0]
+        if rc != 0:
+            raise BackendError(self.lib.mc_host_last_error().decode())
+        self.finalized = True
+        return {f: getattr(r, f) for f, _ in r._fields_}
+
     def pattern(self):
         Cp = np.empty(self.j_cols + 1, np.int32)
         Ci = np.empty(self.nnz, np.int32)
@@ -358,6 +395,42 @@ class HipApi(object):
         ncu, gib = C.c_int(), C.c_double()
         self._chk(self.lib.mc_device_info(self.ctx, name, 256, C.byref(ncu), C.byref(gib)))
         return name.value.decode(), ncu.value, gib.value
+
+
+class _DevicePtr(object):
+    """n doubles of device memory at `ptr` as seen through the CUDA array interface (torch.as_tensor aliases it)"""
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f8", data=(int(ptr), False), version=2, strides=None)
+
+
+def torch_collectives(device, through_host=False):
+    """(allreduce, broadcast) for HipApi.optimize_sharded from torch.distributed's default process group: RCCL on the device
+    buffer itself (backend "nccl"), or -- through_host=True, for a gloo group (CPU rehearsal of the N-rank path on one
+    GPU) -- staged through host memory."""
+    import torch
+    import torch.distributed as dist
+
+    def allreduce(ptr, n):
+        t = torch.as_tensor(_DevicePtr(ptr, n), device=device)
+        if through_host:
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+            torch.cuda.synchronize(device)
+        else:
+            dist.all_reduce(t)
+            torch.cuda.synchronize(device)
+
+    def broadcast(ptr, n, root):
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(int(n),))
+        if through_host:
+            t = torch.from_numpy(a)
+            dist.broadcast(t, src=root)
+        else:
+            t = torch.from_numpy(a).to(device)
+            dist.broadcast(t, src=root)
+            a[:] = t.cpu().numpy()
+    return allreduce, broadcast
 
 
 def host_threads():

@@ -28,54 +28,38 @@
 #include <hip/hip_runtime.h>
 
 #include "../hip_linear_system_solver.hpp"
+#include "lm_core.hpp"
 
 namespace multical_amd {
 
-struct MinimiserSettings {
-  double stepTolerance = 1e-3;         // stop when max |dx| falls to this           (Optimizer2Options::convergenceDeltaX)
-  double costRatioTolerance = 1e-5;    // ... or |cost change| / cost falls to this  (convergenceJDescentRatioThreshold)
-  int maxSteps = 20;                   // bound on evaluated trials and on failed ones alike (maxIterations)
-  bool damped = true;                  // Levenberg-Marquardt; false: Gauss-Newton
-  double initialDamping = 1e-3;
-  bool transposeBackend = false;       // J^T in compressed columns + host J^T J instead of the fused block build
-  bool verbose = false;
-};
-struct MinimiserReport {
-  double costStart = 0, costFinal = 0, lastStep = 0, lastCostChange = 0;
-  int trials = 0, failures = 0;
-  bool solverFailed = false;
-  double secondsSetup = 0, secondsTrials = 0, secondsAdopt = 0, secondsSolve = 0, secondsUpdate = 0;
-  double factorNnz = 0, factorFlops = 0;
-};
-
 namespace detail {
-struct Stopwatch {
-  explicit Stopwatch(double& acc) : acc_(acc), t0_(std::chrono::steady_clock::now()) {}
-  ~Stopwatch() { acc_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); }
-  double& acc_;
-  std::chrono::steady_clock::time_point t0_;
-};
 inline void hipOk(hipError_t e, const char* what) {
   if (e != hipSuccess) throw Exception(std::string(what) + ": " + hipGetErrorString(e));
 }
 }  // namespace detail
 
-// Where cost, normal equations and the step come from.  A trial is evaluated at the state the context holds.
-class NormalEquations {
- public:
-  virtual ~NormalEquations() {}
-  virtual void prepare(bool damped) = 0;                              // sizes, pattern, symbolic factorisation
-  virtual double trial() = 0;                                         // cost at the current state (may linearise on the side)
-  virtual void adopt() = 0;                                           // the last trial's linearisation becomes the system
-  virtual bool step(double damping, std::vector<double>& dx) = 0;     // (H + damping^2 I) dx = rhs on the adopted system
-  virtual const std::vector<double>& gradient() const = 0;            // rhs = -J^T e of the adopted system
-  virtual void factorStats(double& nnz, double& flops) { nnz = flops = 0; }
+// What a sharded run (mc_set_shard, one process per GPU) adds: the caller's collectives.  Every rank's context holds the
+// terms of its own time window; pattern and numbering are global, so partial results add element-wise.
+//   allreduce  in-place sum over the ranks of n doubles in DEVICE memory (RCCL through torch.distributed in the Python
+//              binding; anything else that sums a device buffer)
+//   broadcast  n doubles of HOST memory from rank `root` to every rank
+// Both return 0 on success.  The minimiser calls them in the same order on every rank.
+struct ShardHooks {
+  int rank = 0, world = 1;
+  int (*allreduce)(void* user, double* device_buf, long long n) = nullptr;
+  int (*broadcast)(void* user, double* host_buf, long long n, int root) = nullptr;
+  void* user = nullptr;
+  bool active() const { return world > 1; }
 };
 
 // The fused GPU path: two device systems (adopted / trial), one pinned host image for the factorisation.
+// With shards (Optimizer2::optimize over time-window shards): a trial's cost is summed over the ranks at once
+// (one double); its partial normal equations stay on the device and are summed only if the trial's linearisation is
+// adopted (one all-reduce of the value array and the gradient per ADOPTED step, none for a rejected one); rank 0 factorises
+// and solves, the step is broadcast, and every rank applies the same update to its replica of the state.
 class FusedBlockEquations : public NormalEquations {
  public:
-  explicit FusedBlockEquations(mc_context* ctx) : ctx_(ctx) {}
+  explicit FusedBlockEquations(mc_context* ctx, ShardHooks hooks = ShardHooks()) : ctx_(ctx), hooks_(hooks) {}
   ~FusedBlockEquations() override {
     for (int k = 0; k < 2; ++k) { if (dH_[k]) (void)hipFree(dH_[k]); if (dG_[k]) (void)hipFree(dG_[k]); }
     if (dCost_) (void)hipFree(dCost_);
@@ -104,13 +88,26 @@ class FusedBlockEquations : public NormalEquations {
       detail::hipOk(hipMemset(dH_[k], 0, sizeof(double) * (size_t)nnz_), "hipMemset(system values)");
       detail::hipOk(hipMemset(dG_[k], 0, sizeof(double) * (size_t)n_), "hipMemset(gradient)");
     }
-    detail::hipOk(hipMalloc((void**)&dCost_, sizeof(double)), "hipMalloc(cost)");
+    detail::hipOk(hipMalloc((void**)&dCost_, 2 * sizeof(double)), "hipMalloc(cost)");
     detail::hipOk(hipHostMalloc((void**)&hH_, sizeof(double) * (size_t)nnz_, hipHostMallocDefault), "hipHostMalloc(system image)");
     g_.assign(n_, 0.0);
   }
   double trial() override {
     const int t = 1 - cur_;
     ok(mc_evaluate_error_and_build_system_device(ctx_, 1, dCost_, nullptr, dH_[t], dG_[t], nullptr));
+    if (hooks_.active()) {
+      // the device status travels with the cost, so that every rank sees a failure of any rank and all of them throw together
+      // (a rank that threw alone would leave the others waiting in the next collective)
+      const int st = mc_device_status(ctx_);
+      const double flag = st != 0 ? 1.0 : 0.0;
+      detail::hipOk(hipMemcpy(dCost_ + 1, &flag, sizeof(double), hipMemcpyHostToDevice), "status flag");
+      if (hooks_.allreduce(hooks_.user, dCost_, 2) != 0) throw Exception("sharded minimiser: all-reduce of the cost failed");
+      double both[2] = {0.0, 0.0};
+      detail::hipOk(hipMemcpy(both, dCost_, 2 * sizeof(double), hipMemcpyDeviceToHost), "cost read-back");
+      if (both[1] != 0.0) throw Exception(st != 0 ? mc_last_error(ctx_) : "a device error was raised on another rank");
+      trialPending_ = true;
+      return both[0];
+    }
     double cost = 0.0;
     detail::hipOk(hipMemcpy(&cost, dCost_, sizeof(double), hipMemcpyDeviceToHost), "cost read-back");
     if (mc_device_status(ctx_) != 0) throw Exception(mc_last_error(ctx_));   // the reference throws out of evaluateError
@@ -125,6 +122,11 @@ class FusedBlockEquations : public NormalEquations {
     if (!trialPending_) return;
     trialPending_ = false;
     cur_ = 1 - cur_;
+    if (hooks_.active()) {
+      // the ranks' partial systems become the whole one, identical on every rank
+      if (hooks_.allreduce(hooks_.user, dH_[cur_], nnz_) != 0 || hooks_.allreduce(hooks_.user, dG_[cur_], n_) != 0)
+        throw Exception("sharded minimiser: all-reduce of the normal equations failed");
+    }
     detail::hipOk(hipMemcpy(hH_, dH_[cur_], sizeof(double) * (size_t)nnz_, hipMemcpyDeviceToHost), "system read-back");
     detail::hipOk(hipMemcpy(g_.data(), dG_[cur_], sizeof(double) * (size_t)n_, hipMemcpyDeviceToHost), "gradient read-back");
   }
@@ -132,21 +134,33 @@ class FusedBlockEquations : public NormalEquations {
     // the diagonal entry of column c is the last one of the column (upper triangle in compressed columns)
     if (damped_) for (int c = 0; c < n_; ++c) hH_[colEnd_[c + 1] - 1] += damping * damping;
     dx.assign(n_, 0.0);
-    bool good = chol_.factorize(hH_);
-    if (good) {
-      chol_.solve(g_.data(), dx.data());
-      for (double v : dx) if (!std::isfinite(v)) { good = false; break; }
+    bool good = true;
+    if (!hooks_.active() || hooks_.rank == 0) {   // with shards: one factorisation, on rank 0
+      good = chol_.factorize(hH_);
+      if (good) {
+        chol_.solve(g_.data(), dx.data());
+        for (double v : dx) if (!std::isfinite(v)) { good = false; break; }
+      }
+    }
+    if (hooks_.active()) {
+      dx.push_back(good ? 1.0 : 0.0);
+      if (hooks_.broadcast(hooks_.user, dx.data(), (long long)dx.size(), 0) != 0) throw Exception("sharded minimiser: broadcast of the step failed");
+      good = dx.back() != 0.0;
+      dx.pop_back();
     }
     // the reference relieves the diagonal by the damping, not by its square; the difference stays until the next adoption
     if (damped_) for (int c = 0; c < n_; ++c) hH_[colEnd_[c + 1] - 1] -= damping;
     return good;
   }
   const std::vector<double>& gradient() const override { return g_; }
+  void applyUpdate(const std::vector<double>& dx) override { ok(mc_apply_update(ctx_, dx.data())); }
+  void revertUpdate() override { ok(mc_revert_update(ctx_)); }
   void factorStats(double& nnz, double& flops) override { nnz = (double)chol_.stats().nnz_factor; flops = chol_.stats().flops; }
 
  private:
   void ok(int rc) const { if (rc < 0) throw Exception(mc_last_error(ctx_)); }
   mc_context* ctx_;
+  ShardHooks hooks_;
   bool damped_ = true, trialPending_ = false;
   int n_ = 0, nnz_ = 0, cur_ = 0;
   double* dH_[2] = {nullptr, nullptr};
@@ -162,118 +176,29 @@ class FusedBlockEquations : public NormalEquations {
 // linearisation is formed when it is adopted, at the state the trial was evaluated at.
 class TransposeEquations : public NormalEquations {
  public:
-  explicit TransposeEquations(mc_context* ctx) : s_(ctx) {}
+  explicit TransposeEquations(mc_context* ctx) : ctx_(ctx), s_(ctx) {}
   void prepare(bool damped) override { s_.initMatrixStructure(damped); }
   double trial() override { return s_.evaluateError(1, true); }
   void adopt() override { s_.buildSystem(1, true); }
   bool step(double damping, std::vector<double>& dx) override { s_.setConstantConditioner(damping); return s_.solveSystem(dx); }
   const std::vector<double>& gradient() const override { return s_.rhs(); }
+  void applyUpdate(const std::vector<double>& dx) override { if (mc_apply_update(ctx_, dx.data()) < 0) throw Exception(mc_last_error(ctx_)); }
+  void revertUpdate() override { if (mc_revert_update(ctx_) < 0) throw Exception(mc_last_error(ctx_)); }
 
  private:
+  mc_context* ctx_;
   HipSparseCholeskyLinearSystemSolver s_;
 };
 
-// Nielsen's damping rule as the reference parametrises it (LevenbergMarquardtTrustRegionPolicy.cpp:7-13, 61-84)
-struct DampingSchedule {
-  double damping, growth = 2.0;
-  static constexpr double kShrinkFloor = 1.0 / 3.0, kBeta = 2.0;
-  static constexpr int kPower = 3;
-  explicit DampingSchedule(double d0) : damping(d0) {}
-  void trialRejected() { growth *= 2.0; damping *= growth; }
-  void noGain() { growth *= 10.0; damping *= growth; }
-  void gained(double ratio) {
-    if (damping > 1e-16) {
-      const double byGain = 1.0 - (kBeta - 1.0) * std::pow(2.0 * ratio - 1.0, kPower);
-      damping *= kShrinkFloor > byGain ? kShrinkFloor : byGain;
-      growth = kBeta;
-    } else {
-      damping = 1e-15;
-    }
-  }
-};
-
-inline MinimiserReport minimise(mc_context* ctx, const MinimiserSettings& cfg) {
+// The minimiser on the problem held by ctx: one unsharded context, or -- with hooks -- this rank's shard of it.
+inline MinimiserReport minimise(mc_context* ctx, const MinimiserSettings& cfg, ShardHooks hooks = ShardHooks()) {
   if (!ctx) throw Exception("minimise: null context");
-  MinimiserReport rep;
   std::unique_ptr<NormalEquations> eq;
-  if (cfg.transposeBackend) eq.reset(new TransposeEquations(ctx));
-  else eq.reset(new FusedBlockEquations(ctx));
-  { detail::Stopwatch w(rep.secondsSetup); eq->prepare(cfg.damped); }
-
-  double cost;
-  { detail::Stopwatch w(rep.secondsTrials); cost = eq->trial(); }
-  rep.costStart = cost;
-  double accepted = cost;              // cost of the state the context would fall back to
-  double gainFrom = cost, gainTo = cost;   // the two most recent accepted costs, as seen at the start of an undisturbed iteration
-  double step = cfg.stepTolerance + 1.0, ratio = cfg.costRatioTolerance + 1.0, change = 0.0;
-  bool disturbed = false;              // the previous iteration ended in a rejected trial or a failed factorisation
-  bool haveSystem = false;
-  DampingSchedule lm(cfg.initialDamping);
-  std::vector<double> dx;
-
-  auto unfinished = [&]() {
-    const bool moving = step > cfg.stepTolerance && std::fabs(ratio) > cfg.costRatioTolerance;
-    return rep.trials < cfg.maxSteps && rep.failures < cfg.maxSteps && (moving || rep.solverFailed);
-  };
-  while (unfinished()) {
-    // ---- which system, which damping
-    if (!disturbed) { gainFrom = gainTo; gainTo = cost; }
-    if (!haveSystem || !cfg.damped) {
-      detail::Stopwatch w(rep.secondsAdopt);
-      eq->adopt();
-      haveSystem = true;
-    } else if (disturbed) {
-      lm.trialRejected();
-    } else {
-      // gain ratio of the step just accepted: actual decrease over the decrease the damped model predicted
-      const std::vector<double>& g = eq->gradient();
-      double predicted = 0.0;
-      for (std::size_t i = 0; i < dx.size(); ++i) predicted += dx[i] * (lm.damping * dx[i] + g[i]);
-      const double gain = (gainFrom - gainTo) / predicted;
-      if (gain <= 0) {
-        lm.noGain();                   // accepted, but the old linearisation is kept
-      } else {
-        { detail::Stopwatch w(rep.secondsAdopt); eq->adopt(); }
-        lm.gained(gain);
-      }
-    }
-    // ---- step
-    bool solved;
-    { detail::Stopwatch w(rep.secondsSolve); solved = eq->step(cfg.damped ? lm.damping : 0.0, dx); }
-    if (!solved) {
-      if (cfg.verbose) std::printf("[multical_amd] factorisation failed (damping %g)\n", lm.damping);
-      disturbed = true;
-      rep.solverFailed = true;
-      ++rep.failures;
-      continue;
-    }
-    { detail::Stopwatch w(rep.secondsUpdate); if (mc_apply_update(ctx, dx.data()) < 0) throw Exception(mc_last_error(ctx)); }
-    step = 0.0;
-    for (double v : dx) step = std::fmax(step, std::fabs(v));
-    // ---- trial
-    { detail::Stopwatch w(rep.secondsTrials); cost = eq->trial(); }
-    change = accepted - cost;
-    ratio = change / accepted;
-    const bool worse = ratio < 0.0;
-    if (worse && cfg.damped) {
-      detail::Stopwatch w(rep.secondsUpdate);
-      if (mc_revert_update(ctx) < 0) throw Exception(mc_last_error(ctx));
-      ++rep.failures;
-      disturbed = true;
-    } else {
-      accepted = cost;
-      disturbed = false;
-    }
-    ++rep.trials;
-    if (cfg.verbose)
-      std::printf("[multical_amd] trial %d: cost %.10g (%+.3g), max|dx| %.3g, damping %.3g%s\n", rep.trials, cost, -change, step,
-                  cfg.damped ? lm.damping : 0.0, (worse && cfg.damped) ? "  -> rejected" : "");
-  }
-  rep.costFinal = accepted;
-  rep.lastStep = step;
-  rep.lastCostChange = change;
-  eq->factorStats(rep.factorNnz, rep.factorFlops);
-  return rep;
+  if (cfg.transposeBackend) {
+    if (hooks.active()) throw Exception("the J^T backend is single-GPU");
+    eq.reset(new TransposeEquations(ctx));
+  } else eq.reset(new FusedBlockEquations(ctx, hooks));
+  return minimise(eq.get(), cfg);
 }
 
 }  // namespace multical_amd

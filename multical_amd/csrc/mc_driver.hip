@@ -27,21 +27,24 @@ void mc_optimizer_options_default(mc_optimizer_options* o) {
   o->linearSolver = MC_SOLVER_BLOCK_CHOLESKY;
 }
 
-int mc_optimize(mc_context* ctx, const mc_optimizer_options* opt, mc_solution_return_value* out) {
+static int optimizeImpl(mc_context* ctx, const mc_optimizer_options* opt, mc_solution_return_value* out, ShardHooks hooks, bool sharded) {
   try {
     if (!ctx || !opt || !out) throw Exception("mc_optimize: null argument");
     {
-      // a sharded context returns this rank's partial cost, H and rhs: factorising those would apply a wrong step silently
       int rank = 0, world = 1;
-      if (mc_shard_info(ctx, &rank, &world) == 0 && world > 1)
+      mc_shard_info(ctx, &rank, &world);
+      if (!sharded && world > 1)
+        // a sharded context returns this rank's partial cost, H and rhs: factorising those would apply a wrong step silently
         throw Exception("mc_optimize drives one unsharded context; with mc_set_shard(world > 1) use mc_optimize_sharded, "
-                        "which sums the shared entries, the gradient and the cost over the ranks between build and solve");
+                        "which sums the cost, the normal equations and the step over the ranks");
+      hooks.rank = rank; hooks.world = world;
+      if (sharded && world > 1 && (!hooks.allreduce || !hooks.broadcast)) throw Exception("mc_optimize_sharded: both callbacks are required");
     }
     MinimiserSettings cfg;
     cfg.stepTolerance = opt->convergenceDeltaX;
     cfg.costRatioTolerance = opt->convergenceJDescentRatioThreshold;
     cfg.maxSteps = opt->maxIterations;
-    cfg.verbose = opt->verbose != 0;
+    cfg.verbose = opt->verbose != 0 && hooks.rank == 0;
     cfg.initialDamping = opt->levenbergMarquardtLambdaInit;
     switch (opt->trustRegionPolicy) {
       case MC_POLICY_LEVENBERG_MARQUARDT: cfg.damped = true; break;
@@ -53,7 +56,7 @@ int mc_optimize(mc_context* ctx, const mc_optimizer_options* opt, mc_solution_re
       case MC_SOLVER_SPARSE_CHOLESKY: cfg.transposeBackend = true; break;
       default: throw Exception("mc_optimize: unknown linearSolver");
     }
-    const MinimiserReport r = minimise(ctx, cfg);
+    const MinimiserReport r = minimise(ctx, cfg, hooks);
     std::memset(out, 0, sizeof *out);
     out->JStart = r.costStart; out->JFinal = r.costFinal;
     out->iterations = r.trials; out->failedIterations = r.failures;
@@ -71,6 +74,17 @@ int mc_optimize(mc_context* ctx, const mc_optimizer_options* opt, mc_solution_re
     g_driver_error = e.what();
     return -1;
   }
+}
+
+int mc_optimize(mc_context* ctx, const mc_optimizer_options* opt, mc_solution_return_value* out) {
+  return optimizeImpl(ctx, opt, out, ShardHooks(), false);
+}
+
+int mc_optimize_sharded(mc_context* ctx, const mc_optimizer_options* opt, mc_solution_return_value* out, mc_allreduce_sum_fn allreduce,
+                        mc_broadcast_fn broadcast, void* user) {
+  ShardHooks h;
+  h.allreduce = allreduce; h.broadcast = broadcast; h.user = user;
+  return optimizeImpl(ctx, opt, out, h, true);
 }
 
 }  // extern "C"

@@ -5,12 +5,15 @@
 // product path is the HIP library only.
 #include <memory>
 #include "../../multical_amd/csrc/mc_describe.hpp"
+#include "../../multical_amd/csrc/host/block_cholesky.hpp"
+#include "../../multical_amd/csrc/host/lm_core.hpp"
 
 using namespace mc;
 
 struct Probe {
   Problem P;
   std::string err;
+  std::vector<double> x_prev;   // one-level undo of the state (DesignVariable::revertUpdate)
   // host copies of per-batch offset arrays (the device path uploads the same)
   std::vector<std::vector<int>> obs_q_off, obs_t_off, term_q_off, term_t_off;
   std::vector<int> term_batch, term_local;
@@ -358,3 +361,135 @@ int probe_motion_q(void* h, int which, double* out, int N) {
 }
 }
 #include "cpu_optimised.inc"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host twin of the N-rank iteration (mc_optimize_sharded): the SAME loop (multical_amd/csrc/host/lm_core.hpp) and the same
+// factorisation (host/block_cholesky.hpp) over the g++ build of the term math, so that world_size-2 gloo ranks can run
+// Optimizer2::optimize over time-window shards on CPUs.  The state update restates k_update (mc_kernels.hip).
+static void twinApplyUpdate(Probe* pr, const double* dx) {
+  Problem& P = pr->P;
+  pr->x_prev = P.x;
+  for (int dvi : P.update_dvs) {
+    const DvRec& u = P.dvs[dvi];
+    const double* d = dx + u.col;
+    double* p = &P.x[u.off];
+    if (u.kind == DV_ROTATION_QUATERNION || u.kind == DV_HOMOGENEOUS_POINT) {
+      const double dq[3] = {d[0] * u.scaling, d[1] * u.scaling, d[2] * u.scaling};
+      const double q[4] = {p[0], p[1], p[2], p[3]};
+      double o[4];
+      update_quat(q, dq, o);
+      for (int k = 0; k < 4; ++k) p[k] = o[k];
+    } else if (u.kind == DV_EUCLIDEAN_DIRECTION) {
+      double R[9], Cm[9], O[9];
+      ypr0_to_r(d[0] * u.scaling, d[1] * u.scaling, R);
+      for (int k = 0; k < 9; ++k) Cm[k] = p[k];
+      m3_mult(Cm, R, O);
+      for (int k = 0; k < 9; ++k) p[k] = O[k];
+    } else if (u.kind == DV_MATRIX_BASIC) {
+      int k = 0;
+      for (int idx = 0; idx < 9; ++idx) if ((u.mask >> idx) & 1) p[idx] += d[k++] * u.scaling;
+    } else {
+      for (int k = 0; k < u.dim; ++k) p[k] += d[k] * u.scaling;
+    }
+  }
+}
+typedef int (*twin_allreduce_fn)(void* user, double* buf, long long n);
+typedef int (*twin_broadcast_fn)(void* user, double* buf, long long n, int root);
+extern "C" int probe_cpu_optimised(void* h, int useM, int build, int n_threads, double* Cx, double* rhs, double* J_out);
+
+namespace {
+class TwinEquations : public multical_amd::NormalEquations {
+ public:
+  TwinEquations(Probe* pr, int threads, twin_allreduce_fn ar, twin_broadcast_fn bc, void* user) : pr_(pr), threads_(threads), ar_(ar), bc_(bc), user_(user) {}
+  void prepare(bool damped) override {
+    damped_ = damped;
+    Problem& P = pr_->P;
+    n_ = P.j_cols; nnz_ = P.nnz;
+    std::vector<int> base(P.n_blocks + 1, 0);
+    for (int b = 0; b < P.n_blocks; ++b) base[b + 1] = base[b] + P.block_dim[b];
+    chol_.analyze(n_, P.Cp.data(), P.Ci.data(), P.n_blocks, base.data());
+    for (int k = 0; k < 2; ++k) { H_[k].assign(nnz_, 0.0); G_[k].assign(n_, 0.0); }
+    image_.assign(nnz_, 0.0);
+    g_.assign(n_, 0.0);
+  }
+  double trial() override {
+    const int t = 1 - cur_;
+    double cost[2] = {0.0, 0.0};
+    if (probe_cpu_optimised(pr_, 1, 1, threads_, H_[t].data(), G_[t].data(), &cost[0]) != 0) cost[1] = 1.0;   // the failure travels with the cost
+    if (sharded() && ar_(user_, cost, 2) != 0) throw std::runtime_error("all-reduce of the cost failed");
+    if (cost[1] != 0.0) throw std::runtime_error(pr_->err.empty() ? "a term failed on another rank" : pr_->err);
+    pending_ = true;
+    return cost[0];
+  }
+  void adopt() override {
+    if (!pending_) return;
+    pending_ = false;
+    cur_ = 1 - cur_;
+    if (sharded() && (ar_(user_, H_[cur_].data(), nnz_) != 0 || ar_(user_, G_[cur_].data(), n_) != 0))
+      throw std::runtime_error("all-reduce of the normal equations failed");
+    image_ = H_[cur_];
+    g_ = G_[cur_];
+  }
+  bool step(double damping, std::vector<double>& dx) override {
+    const std::vector<int>& Cp = pr_->P.Cp;
+    if (damped_) for (int c = 0; c < n_; ++c) image_[Cp[c + 1] - 1] += damping * damping;
+    dx.assign(n_, 0.0);
+    bool good = true;
+    if (!sharded() || pr_->P.rank == 0) {
+      good = chol_.factorize(image_.data());
+      if (good) {
+        chol_.solve(g_.data(), dx.data());
+        for (double v : dx) if (!std::isfinite(v)) { good = false; break; }
+      }
+    }
+    if (sharded()) {
+      dx.push_back(good ? 1.0 : 0.0);
+      if (bc_(user_, dx.data(), (long long)dx.size(), 0) != 0) throw std::runtime_error("broadcast of the step failed");
+      good = dx.back() != 0.0;
+      dx.pop_back();
+    }
+    if (damped_) for (int c = 0; c < n_; ++c) image_[Cp[c + 1] - 1] -= damping;   // the reference's residue (BlockCholeskyLinearSystemSolver.cpp:92-97)
+    return good;
+  }
+  const std::vector<double>& gradient() const override { return g_; }
+  void applyUpdate(const std::vector<double>& dx) override { twinApplyUpdate(pr_, dx.data()); }
+  void revertUpdate() override { pr_->P.x = pr_->x_prev; }
+
+ private:
+  bool sharded() const { return pr_->P.world > 1; }
+  Probe* pr_;
+  int threads_;
+  twin_allreduce_fn ar_;
+  twin_broadcast_fn bc_;
+  void* user_;
+  bool damped_ = true, pending_ = false;
+  int n_ = 0, nnz_ = 0, cur_ = 0;
+  std::vector<double> H_[2], G_[2], image_, g_;
+  multical_amd::BlockSparseCholesky chol_;
+};
+}  // namespace
+
+extern "C" {
+// out5: JStart, JFinal, iterations, failedIterations, linearSolverFailure
+int probe_optimize(void* h, int max_iterations, double lambda0, double dx_tol, double ratio_tol, int damped, int n_threads,
+                   twin_allreduce_fn ar, twin_broadcast_fn bc, void* user, double* out5) {
+  Probe* pr = (Probe*)h;
+  PR_TRY
+  multical_amd::MinimiserSettings cfg;
+  cfg.maxSteps = max_iterations; cfg.initialDamping = lambda0; cfg.stepTolerance = dx_tol; cfg.costRatioTolerance = ratio_tol;
+  cfg.damped = damped != 0;
+  TwinEquations eq(pr, n_threads, ar, bc, user);
+  const multical_amd::MinimiserReport r = multical_amd::minimise(&eq, cfg);
+  out5[0] = r.costStart; out5[1] = r.costFinal; out5[2] = r.trials; out5[3] = r.failures; out5[4] = r.solverFailed ? 1.0 : 0.0;
+  return 0;
+  PR_CATCH(pr, -1)
+}
+int probe_get_dv_params(void* h, int dv, double* out) {
+  Probe* pr = (Probe*)h;
+  if (dv < 0 || dv >= (int)pr->P.dvs.size()) return -1;
+  const DvRec& d = pr->P.dvs[dv];
+  for (int k = 0; k < d.nparam; ++k) out[k] = pr->P.x[d.off + k];
+  return d.nparam;
+}
+int probe_spline_first_dv(void* h, int sid) { return ((Probe*)h)->P.splines[sid].first_dv; }
+}

@@ -192,3 +192,46 @@ class ProbeApi(object):
         f = np.zeros(self.n_terms, np.int32)
         self.L.probe_my_terms(self.h, _i(f))
         return f.astype(bool)
+
+    def dv_params(self, dv):
+        out = np.zeros(16)
+        n = self.L.probe_get_dv_params(self.h, C.c_int(int(dv)), _d(out))
+        return out[:n].copy()
+
+    def spline_first_dv(self, sid):
+        return self.L.probe_spline_first_dv(self.h, C.c_int(int(sid)))
+
+    def optimize(self, max_iterations, lambda0, dx_tol, ratio_tol, damped=True, n_threads=1, allreduce=None, broadcast=None):
+        """Host twin of mc_optimize / mc_optimize_sharded (tests/hostprobe: the product's minimiser loop and factorisation over
+        the g++ build of the term math).  allreduce(array) sums a float64 numpy array over the ranks in place,
+        broadcast(array, root) sends it from rank root; both only needed for a sharded probe."""
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_longlong)
+        BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_longlong, C.c_int)
+        failure = []
+
+        def _ar(user, ptr, n):
+            try:
+                allreduce(np.ctypeslib.as_array(ptr, shape=(int(n),)))
+                return 0
+            except Exception as ex:
+                failure.append(ex)
+                return -1
+
+        def _bc(user, ptr, n, root):
+            try:
+                broadcast(np.ctypeslib.as_array(ptr, shape=(int(n),)), int(root))
+                return 0
+            except Exception as ex:
+                failure.append(ex)
+                return -1
+        ar, bc = AR(_ar), BC(_bc)
+        out = np.zeros(5)
+        self.L.probe_optimize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, AR, BC, C.c_void_p,
+                                          C.POINTER(C.c_double)]
+        rc = self.L.probe_optimize(self.h, int(max_iterations), float(lambda0), float(dx_tol), float(ratio_tol), int(bool(damped)),
+                                   int(n_threads), ar, bc, None, _d(out))
+        if failure:
+            raise failure[0]
+        self._chk(rc)
+        return dict(JStart=out[0], JFinal=out[1], iterations=int(out[2]), failedIterations=int(out[3]), linearSolverFailure=int(out[4]))
+
