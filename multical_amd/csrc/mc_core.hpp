@@ -93,6 +93,25 @@ struct Batch {
   std::vector<GroupRec> groups;       // all groups (terms numbered within the batch)
   std::vector<GroupRec> my_groups;    // the groups of this rank's time window
   std::vector<double> group_time;     // representative time per group (for sharding)
+  // Static reprojection batches with landmark design variables.  `groups` holds one group per term over an active landmark
+  // (footprint = the observation's blocks + the landmark: what the pattern, the J^T layout and the shard marks are built
+  // from).  The evaluate / build kernel does not run one workgroup pass per such term: it takes the observation as ONE
+  // group (obs_groups, footprint without the landmark) and adds a term's landmark rows x [core columns | landmark |
+  // residual] products through the term's own footprint, term_fp[term] (-1: constant or inactive point).
+  std::vector<GroupRec> obs_groups, my_obs_groups;
+  std::vector<int> term_fp;
+  // ... and the products of a landmark's rows with the camera-level columns (baselines, intrinsics), with themselves and with
+  // the residual meet EVERY observation of that landmark: adding them per term would queue thousands of atomics on the same
+  // entries.  They are formed in a second, landmark-major pass instead: lm_terms lists this rank's terms by landmark,
+  // lm_groups cuts the lists into work items (term_first = offset into lm_terms; fp = camera-level blocks + landmark).
+  std::vector<std::pair<int, int>> lm_fp;   // (landmark dv, footprint), sorted by dv
+  // per term over an active landmark, where its landmark x target-pose blocks sit in the value array (the observation-major
+  // pass adds them per term): [value offset of the (landmark, q_t_c) block pair, of (landmark, t_t_c)] (-1: not active) and
+  // [2 h + o] for each, h = column height of the pair's column block, o = 1 when the landmark is the column block
+  std::vector<int> lm_slots;
+  std::vector<int> lm_terms;
+  std::vector<GroupRec> lm_groups;
+  enum { LM_GROUP_TERMS = 1024 };
   // stream kinds (lidar / IMU): time-sorted order, per-term frozen coefficient buffer, chunks
   std::vector<int> order, term_lo, term_nbuf;
   std::vector<ChunkRec> chunks, my_chunks;
@@ -128,6 +147,19 @@ struct Problem {
   std::vector<Batch> batches;
   int rank = 0, world = 1;
   double shard_lo = -INFINITY, shard_hi = INFINITY;
+  std::vector<double> shard_cuts;   // world + 1 window boundaries: rank r takes the work items with time in [cuts[r], cuts[r + 1])
+  int shardOf(double t) const { int r = 0; while (r + 1 < world && t >= shard_cuts[r + 1]) ++r; return r; }
+  // A BSplineMotionError term covers a whole spline.  Its sums are split by coefficient: the rank whose window holds the
+  // middle of coefficient i's support takes band column i of Q (blocks (i - d, i)), row i of Q c and c_i^T (Q c)_i.
+  // Knots are non-decreasing, so a rank's coefficients are the contiguous range [lo, hi).
+  void motionRange(const SplineRec& s, int rnk, int& lo, int& hi) const {
+    lo = 0; hi = s.n_coeff;
+    if (world <= 1) return;
+    lo = hi = -1;
+    for (int i = 0; i < s.n_coeff; ++i)
+      if (shardOf(knots[s.knots_off + i + s.order / 2]) == rnk) { if (lo < 0) lo = i; hi = i + 1; }
+    if (lo < 0) lo = hi = 0;
+  }
 
   // structure
   bool finalized = false;
@@ -471,7 +503,7 @@ inline void Problem::finalize() {
   auto blk = [&](int dv) { return dv >= 0 ? dvs[dv].block : -1; };
   // ---- groups + footprints per batch
   for (Batch& b : batches) {
-    b.groups.clear(); b.group_time.clear();
+    b.groups.clear(); b.group_time.clear(); b.obs_groups.clear(); b.term_fp.clear(); b.lm_fp.clear();
     auto pushGroup = [&](int first, int count, int fp, int aux, double time, int maxTerms) {
       for (int o = 0; o < count; o += maxTerms) {
         b.groups.push_back(GroupRec{first + o, std::min(maxTerms, count - o), fp, aux, 0});
@@ -628,6 +660,26 @@ inline void Problem::finalize() {
     } else if (b.kind == KIND_STATIC_REPROJ) {
       int n_obs = (int)b.obs_first.size() - 1;
       const CameraRec& c = cams[b.cam];
+      if (!b.term_dv_lm.empty()) {
+        // footprint of the landmark-major pass: the camera-level blocks of the batch + the landmark
+        std::vector<int> seen;
+        for (int dv : b.term_dv_lm) if (blk(dv) >= 0) seen.push_back(dv);
+        std::sort(seen.begin(), seen.end());
+        seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+        for (int dv : seen) {
+          std::vector<int> pattern;
+          std::vector<std::array<int, 3>> written;
+          auto add = [&](int role, int d2) { if (blk(d2) >= 0) { pattern.push_back(blk(d2)); written.push_back({role, blk(d2), 1}); } };
+          for (size_t j = 0; j < b.chain_q.size(); ++j) { add(F2_ROLE_CHAIN + 2 * (int)j, b.chain_q[j]); add(F2_ROLE_CHAIN + 2 * (int)j + 1, b.chain_t[j]); }
+          add(F2_ROLE_PROJ, c.dv_proj);
+          if (c.dv_dist >= 0) add(F2_ROLE_DIST, c.dv_dist);
+          add(F2_ROLE_LM, dv);
+          std::sort(pattern.begin(), pattern.end());
+          if (std::adjacent_find(pattern.begin(), pattern.end()) != pattern.end())
+            throw std::invalid_argument("a design variable plays two roles in one error term");
+          b.lm_fp.push_back({dv, internFootprint(pattern, written)});
+        }
+      }
       for (int o = 0; o < n_obs; ++o) {
         std::vector<int> pattern;
         std::vector<std::array<int, 3>> written;
@@ -647,6 +699,8 @@ inline void Problem::finalize() {
         // landmarks that are design variables: a term whose landmark is active has a Jacobian block of its own, so it
         // forms a group of its own (footprint = the observation's blocks + the landmark); runs of terms over constant
         // or inactive points stay together
+        if (b.term_fp.empty()) b.term_fp.assign(b.n_terms, -1);
+        b.obs_groups.push_back(GroupRec{b.obs_first[o], b.obs_first[o + 1] - b.obs_first[o], fp, o, 0});
         int run0 = b.obs_first[o];
         for (int k = b.obs_first[o]; k < b.obs_first[o + 1]; ++k) {
           const int lb = b.term_dv_lm[k] >= 0 ? blk(b.term_dv_lm[k]) : -1;
@@ -658,7 +712,8 @@ inline void Problem::finalize() {
           std::sort(pat2.begin(), pat2.end());
           if (std::adjacent_find(pat2.begin(), pat2.end()) != pat2.end())
             throw std::invalid_argument("a design variable plays two roles in one error term");
-          pushGroup(k, 1, internFootprint(pat2, wr2), o, (double)o, 1 << 30);
+          b.term_fp[k] = internFootprint(pat2, wr2);
+          pushGroup(k, 1, b.term_fp[k], o, (double)o, 1 << 30);
           run0 = k + 1;
         }
         if (b.obs_first[o + 1] > run0) pushGroup(run0, b.obs_first[o + 1] - run0, fp, o, (double)o, 1 << 30);
@@ -819,12 +874,32 @@ inline void Problem::finalize() {
       for (; r < world; ++r) cuts[r] = INFINITY;
     }
     shard_lo = cuts[rank]; shard_hi = cuts[rank + 1];
+    shard_cuts = cuts;
     for (Batch& b : batches) {
       // keep the groups whose time falls into [lo, hi); group order inside a batch is preserved
       std::vector<GroupRec> mine;
       for (size_t g = 0; g < b.groups.size(); ++g)
         if (b.group_time[g] >= shard_lo && b.group_time[g] < shard_hi) mine.push_back(b.groups[g]);
       b.my_groups.swap(mine);
+      b.my_obs_groups.clear();
+      for (const GroupRec& g : b.obs_groups)   // time of a static observation = its index (as for its groups above)
+        if ((double)g.aux >= shard_lo && (double)g.aux < shard_hi) b.my_obs_groups.push_back(g);
+      b.lm_terms.clear(); b.lm_groups.clear();
+      if (!b.lm_fp.empty()) {
+        std::vector<std::vector<int>> by_lm(b.lm_fp.size());
+        for (const GroupRec& g : b.my_obs_groups)
+          for (int k = g.term_first; k < g.term_first + g.term_count; ++k) {
+            if (b.term_fp[k] < 0) continue;
+            auto it = std::lower_bound(b.lm_fp.begin(), b.lm_fp.end(), std::make_pair(b.term_dv_lm[k], -1));
+            by_lm[it - b.lm_fp.begin()].push_back(k);
+          }
+        for (size_t l = 0; l < by_lm.size(); ++l)
+          for (size_t o = 0; o < by_lm[l].size(); o += Batch::LM_GROUP_TERMS) {
+            const int n = (int)std::min<size_t>(Batch::LM_GROUP_TERMS, by_lm[l].size() - o);
+            b.lm_groups.push_back(GroupRec{(int)b.lm_terms.size(), n, b.lm_fp[l].second, (int)l, 0});
+            b.lm_terms.insert(b.lm_terms.end(), by_lm[l].begin() + o, by_lm[l].begin() + o + n);
+          }
+      }
       b.my_chunks.clear();
       b.max_nb = b.max_nob = b.max_g = b.max_terms = b.max_tab = 0;
       const int pose_block0 = (b.spline >= 0 && !b.chunks.empty()) ? dvs[splines[b.spline].first_dv].block : -1;
@@ -873,11 +948,32 @@ inline void Problem::finalize() {
     size_t k = std::lower_bound(rows.begin(), rows.end(), rb) - rows.begin();
     return Cp[block_col[cb]] + col_roff[cb][k];
   };
+  for (Batch& b : batches) {
+    b.lm_slots.clear();
+    if (b.kind != KIND_STATIC_REPROJ || b.term_fp.empty()) continue;
+    b.lm_slots.assign((size_t)4 * b.n_terms, -1);
+    for (const GroupRec& g : b.my_obs_groups)
+      for (int k = g.term_first; k < g.term_first + g.term_count; ++k) {
+        if (b.term_fp[k] < 0) continue;
+        const int lb = blk(b.term_dv_lm[k]);
+        const int pose[2] = {blk(b.obs_dv_q[g.aux]), blk(b.obs_dv_t[g.aux])};
+        for (int i = 0; i < 2; ++i) {
+          if (pose[i] < 0) continue;
+          const int rb = std::min(lb, pose[i]), cb = std::max(lb, pose[i]);
+          b.lm_slots[4 * (size_t)k + i] = slotBase(rb, cb);
+          b.lm_slots[4 * (size_t)k + 2 + i] = 2 * col_h[cb] + (cb == lb ? 1 : 0);
+        }
+      }
+  }
   fp_off.assign(fp_written.size(), 0);
   fp_data.clear();
   // a shard only needs the tables of the footprints its own groups use (a long sequence has millions of footprints)
   std::vector<char> fp_used(fp_written.size(), world == 1 ? 1 : 0);
-  if (world > 1) for (const Batch& b : batches) for (const GroupRec& g : b.my_groups) fp_used[g.fp] = 1;
+  if (world > 1) for (const Batch& b : batches) {
+    for (const GroupRec& g : b.my_groups) fp_used[g.fp] = 1;
+    for (const GroupRec& g : b.my_obs_groups) fp_used[g.fp] = 1;
+    for (const GroupRec& g : b.lm_groups) fp_used[g.fp] = 1;
+  }
   for (size_t f = 0; f < fp_written.size(); ++f) {
     fp_off[f] = (int)fp_data.size();
     if (!fp_used[f]) continue;
@@ -912,31 +1008,7 @@ inline void Problem::finalize() {
   // ---- shared entries (world > 1): owner rank of every block pair over ALL ranks' work items
   shared_idx.clear();
   if (world > 1) {
-    std::vector<double> cutv;   // recover every rank's window: rank r owns [cutv[r], cutv[r+1])
-    {
-      // same cuts as above, recomputed for all ranks
-      struct GT { double t; double cost; };
-      std::vector<GT> all;
-      for (const Batch& b : batches) {
-        double per = b.kind == KIND_REPROJ ? 1.0 : (b.kind == KIND_LIDAR ? 1.5 : (b.kind == KIND_STATIC_REPROJ ? 1.0 : 4.0));
-        for (size_t g = 0; g < b.groups.size(); ++g) all.push_back(GT{b.group_time[g], 8.0 + per * b.groups[g].term_count});
-        for (size_t g = 0; g < b.chunks.size(); ++g) all.push_back(GT{b.chunk_time[g], 8.0 + per * b.chunks[g].term_count});
-      }
-      cutv.assign(world + 1, INFINITY);
-      cutv[0] = -INFINITY;
-      if (!all.empty()) {
-        std::sort(all.begin(), all.end(), [](const GT& a, const GT& b2) { return a.t < b2.t; });
-        double tot = 0;
-        for (auto& g : all) tot += g.cost;
-        double acc = 0;
-        int r = 1;
-        for (size_t i = 0; i < all.size() && r < world; ++i) {
-          acc += all[i].cost;
-          while (r < world && acc >= tot * r / world) { cutv[r] = (i + 1 < all.size()) ? 0.5 * (all[i].t + all[i + 1].t) : INFINITY; ++r; }
-        }
-      }
-    }
-    auto ownerOf = [&](double t) { int r = 0; while (r + 1 < world && t >= cutv[r + 1]) ++r; return r; };
+    auto ownerOf = [&](double t) { return shardOf(t); };   // shard_cuts hold every rank's window
     std::vector<signed char> owner(pat_rows.size(), -1);   // -1 untouched, -2 shared, else rank
     auto mark = [&](int b1, int b2, int r) {
       int rb = std::min(b1, b2), cb = std::max(b1, b2);
@@ -972,7 +1044,10 @@ inline void Problem::finalize() {
         const SplineRec& sp = splines[b.spline];
         int b0 = dvs[sp.first_dv].block;
         if (b0 >= 0)
-          for (int i = 0; i < sp.n_coeff; ++i) for (int d = 0; d < sp.order && i - d >= 0; ++d) mark(b0 + i - d, b0 + i, 0);
+          for (int i = 0; i < sp.n_coeff; ++i) {
+            const int r = shardOf(knots[sp.knots_off + i + sp.order / 2]);   // motionRange()'s rule
+            for (int d = 0; d < sp.order && i - d >= 0; ++d) mark(b0 + i - d, b0 + i, r);
+          }
       }
     }
     for (int cb = 0; cb < n_blocks; ++cb)

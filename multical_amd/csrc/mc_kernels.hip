@@ -1167,10 +1167,25 @@ template <> struct StreamTraits<LidarBatchView> {
     return beta0;
   }
 };
-template <> struct StreamTraits<ImuBatchView> {
+// The two IMU kinds (calibrated: imu_term; scale-misalignment / size-effect: imu_sm_term) share the row layout, the
+// live-window bookkeeping and the compact bias columns; they differ in the term function only.
+template <class View> struct ImuTermFn;
+template <> struct ImuTermFn<ImuBatchView> {
+  template <bool CB> static __device__ __forceinline__ bool run(const ImuBatchView& b, const double* x, int u, bool useM, bool wantJ,
+                                                                const int* rc, double* J, int ld, double* e, TermOut& out) {
+    return imu_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out);
+  }
+};
+template <> struct ImuTermFn<ImuSmBatchView> {
+  template <bool CB> static __device__ __forceinline__ bool run(const ImuSmBatchView& b, const double* x, int u, bool useM, bool wantJ,
+                                                                const int* rc, double* J, int ld, double* e, TermOut& out) {
+    return imu_sm_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out);
+  }
+};
+template <class View> struct ImuStreamTraits {
   enum { D = 3, CO = 36, OCC = MC_STREAM_OCC };
   // first local "other" column and number of columns of the bias (spline window or static point); n = 0: no shortcut
-  template <class V> static __device__ __forceinline__ int biasColumns(const V& b, const int* of, int& n) {
+  static __device__ __forceinline__ int biasColumns(const View& b, const int* of, int& n) {
     const int c0 = of[4 + IMU_ROLE_BIAS];
     n = (c0 >= 0 && b.S == nullptr) ? (b.bias.order > 0 ? 3 * of[3] : 3) : 0;
     return c0;
@@ -1187,7 +1202,7 @@ template <> struct StreamTraits<ImuBatchView> {
   // CB: compact bias columns -- the bias columns are not stored in the rows (the columns behind them move down by their
   // number) and the role column of the bias is the index of the first live coefficient in the term's bias-weight array
   template <bool CB = false>
-  static __device__ __forceinline__ int eval(const ImuBatchView& b, const double* x, int u, bool useM, bool wantJ,
+  static __device__ __forceinline__ int eval(const View& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int, int,
                                              double* J, int ld, double* e, TermOut& out, int* st) {
     int rc[MC_MAX_ROLES];
@@ -1207,55 +1222,12 @@ template <> struct StreamTraits<ImuBatchView> {
       if (!(t >= b.bias.t_min && t <= b.bias.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
       rc[IMU_ROLE_BIAS] += (CB ? 1 : 3) * (spline_segment(b.bias, t) - of[2]);
     }
-    if (!imu_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    if (!ImuTermFn<View>::template run<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     return beta0;
   }
 };
-
-template <> struct StreamTraits<ImuSmBatchView> {
-  enum { D = 3, CO = 36, OCC = MC_STREAM_OCC };
-  // first local "other" column and number of columns of the bias (spline window or static point); n = 0: no shortcut
-  template <class V> static __device__ __forceinline__ int biasColumns(const V& b, const int* of, int& n) {
-    const int c0 = of[4 + IMU_ROLE_BIAS];
-    n = (c0 >= 0 && b.S == nullptr) ? (b.bias.order > 0 ? 3 * of[3] : 3) : 0;
-    return c0;
-  }
-  static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
-    const double2* q = reinterpret_cast<const double2*>(row + 6 * o);   // 16-byte aligned: ld and 6 o are even
-    const double2 a = q[0], b2 = q[1], c = q[2];
-    v[0] = a.x; v[1] = a.y; v[2] = b2.x; v[3] = b2.y; v[4] = c.x; v[5] = c.y;
-  }
-  static __device__ __forceinline__ void pair6(const double* row, int o, int o2, double (&x)[6], double (&y)[6]) {
-    coef6(row, o, x);
-    coef6(row, o2, y);
-  }
-  // CB: compact bias columns -- the bias columns are not stored in the rows (the columns behind them move down by their
-  // number) and the role column of the bias is the index of the first live coefficient in the term's bias-weight array
-  template <bool CB = false>
-  static __device__ __forceinline__ int eval(const ImuSmBatchView& b, const double* x, int u, bool useM, bool wantJ,
-                                             const int* of, int pose_lo, int pose_nb, int, int,
-                                             double* J, int ld, double* e, TermOut& out, int* st) {
-    int rc[MC_MAX_ROLES];
-    const int bias_0 = of[4 + IMU_ROLE_BIAS], bias_n = bias_0 >= 0 ? 3 * (b.bias.order > 0 ? of[3] : 1) : 0;
-#pragma unroll
-    for (int r = 0; r < MC_MAX_ROLES; ++r) {
-      const int c = of[4 + r];
-      rc[r] = c >= 0 ? CO + ((CB && bias_0 >= 0 && c > bias_0) ? c - bias_n : c) : -1;
-    }
-    const double t = b.t[u];
-    if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
-    int beta0 = 0;
-    rc[IMU_ROLE_POSE] = -1;
-    if (pose_nb > 0) { beta0 = spline_segment(b.pose, t) - pose_lo; rc[IMU_ROLE_POSE] = 0; }
-    if (CB && rc[IMU_ROLE_BIAS] >= 0) rc[IMU_ROLE_BIAS] = 0;
-    if (b.bias.order > 0 && rc[IMU_ROLE_BIAS] >= 0) {
-      if (!(t >= b.bias.t_min && t <= b.bias.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
-      rc[IMU_ROLE_BIAS] += (CB ? 1 : 3) * (spline_segment(b.bias, t) - of[2]);
-    }
-    if (!imu_sm_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
-    return beta0;
-  }
-};
+template <> struct StreamTraits<ImuBatchView> : ImuStreamTraits<ImuBatchView> {};
+template <> struct StreamTraits<ImuSmBatchView> : ImuStreamTraits<ImuSmBatchView> {};
 
 template <class View, bool BUILD, bool CB = false>
 __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
@@ -1696,7 +1668,9 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
   const ImageRec run = runs[blockIdx.x];
   const StaticReprojBatchView b = views[groups[run.first].batch];
   const int nch = b.n_chain, pd = b.cam.proj_dim, nd = b.cam.dist_off >= 0 ? 4 : 0;
-  // batches with landmark design variables carry 3 more per-observation columns (a group is then a single term)
+  // batches with landmark design variables carry 3 more columns per row: the landmark of the row's TERM.  The core Gram's
+  // entries over them mix different landmarks and are never flushed (their role is inactive in the observation's
+  // footprint); the landmark's rows of the system are added per term below, through the term's own footprint
   const int L = b.lm_off ? 3 : 0, npo = 6 + L;
   const int ncore = npo + 6 * nch + pd + nd + 1, ecol = ncore - 1;
   const int nt = (ncore + 15) >> 4, ntile = nt * (nt + 1) / 2;
@@ -1742,7 +1716,7 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
       for (int i = tid; i < ntile * 256; i += 256) gram[i] = 0.0;
       if (f.rolecol[F2_ROLE_QTC] >= 0) rc[F2_ROLE_QTC] = 0;
       if (f.rolecol[F2_ROLE_TTC] >= 0) rc[F2_ROLE_TTC] = 3;
-      if (L && f.rolecol[F2_ROLE_LM] >= 0) rc[F2_ROLE_LM] = 6;
+      if (L) rc[F2_ROLE_LM] = 6;
 #pragma unroll
       for (int j = 0; j < F2_MAX_CHAIN; ++j) {
         if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j] >= 0) rc[F2_ROLE_CHAIN + 2 * j] = npo + 6 * j;
@@ -1795,6 +1769,33 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
             acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc[5], 0, 0, 0);
           }
         }
+        if (L && f.rolecol[F2_ROLE_LM] < 0) {
+          // landmark x target pose of this observation: task = (term of the pass, landmark component a, pose column j < 6); the
+          // two block pairs' places in the value array come precomputed per term (Batch::lm_slots).  These entries belong to
+          // one (observation, landmark) pair.  a runs fastest: three consecutive addresses when the landmark block is the row
+          // block.  Everything else of the landmark's rows (x camera-level columns, x itself, rhs) is common to all
+          // observations of the landmark: k_static_lm, landmark-major
+          const int npass = nrows >> 1;
+          // consecutive lanes should meet consecutive addresses: with the landmark as the column block a column holds the 6
+          // pose rows of the observation (j fastest); with the landmark as the row block the rows of a column are the
+          // landmarks, those of neighbouring corners next to one another (a fastest, then the term, j slowest)
+          const int4* slots = reinterpret_cast<const int4*>(b.lm_slots) + gr.term_first + base;
+          const bool lm_is_col = (slots[0].z & 1) != 0 || (slots[0].z < 0 && (slots[0].w & 1) != 0);
+          for (int it = tid; it < npass * 18; it += 256) {
+            int a, j, kk;
+            if (lm_is_col) { j = it % 6; a = (it / 6) % 3; kk = it / 18; }
+            else { a = it % 3; kk = (it / 3) % npass; j = it / (3 * npass); }
+            const int4 sl = slots[kk];
+            const int slot = j < 3 ? sl.x : sl.y, ho = j < 3 ? sl.z : sl.w, jc = j < 3 ? j : j - 3;
+            if (slot < 0) continue;   // constant / inactive point, inactive pose
+            const double* r0 = rows + (2 * kk) * ld;
+            const double m = r0[6 + a] * r0[j] + r0[ld + 6 + a] * r0[ld + j];
+            const int h = ho >> 1;
+            const int addr = (ho & 1) ? slot + a * h + (a * (a + 1)) / 2 + jc     // landmark block = column block
+                                      : slot + jc * h + (jc * (jc + 1)) / 2 + a;  // target-pose block = column block
+            atomic_add_f64(dc.Cx + addr, m);
+          }
+        }
         __syncthreads();   // the row tile is rewritten by the next pass
       }
     }
@@ -1845,6 +1846,103 @@ __global__ __launch_bounds__(256, BUILD ? 2 : 1) void k_static(const StaticRepro
   }
 }
 
+// F2 with landmark design variables, second pass, landmark-major: one 256-thread workgroup per run of <= 1024 terms of ONE
+// landmark in one camera (Batch::lm_groups; the terms come from different observations, so each reads its observation's
+// record from the pre-pass array instead of an LDS copy).  Same rows, same MFMA Gram as k_static; flushed are the landmark's
+// rows only: x camera-level columns (baselines, intrinsics), x itself, and the landmark part of rhs -- one atomic per
+// entry and work item where the observation-major pass would issue one per term on the same few addresses.
+__global__ __launch_bounds__(256, 2) void k_static_lm(const StaticReprojBatchView* __restrict__ views, DevCommon dc,
+                                                      const GroupRec* __restrict__ lm_groups, const F2Common* __restrict__ common, int ld) {
+  extern __shared__ double rows[];   // 256 x ld
+  __shared__ double gram[6 * 256];   // upper tile pairs, [tile][reg][lane] = the MFMA C/D layout
+  __shared__ int lcol[F2_MAXCORE];
+  typedef double f64x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  const GroupRec gr = lm_groups[blockIdx.x];
+  const StaticReprojBatchView b = views[gr.batch];
+  const FpView f = fp_view(dc, gr.fp);
+  const int nch = b.n_chain, pd = b.cam.proj_dim, nd = b.cam.dist_off >= 0 ? 4 : 0;
+  const int npo = 9, ncore = npo + 6 * nch + pd + nd + 1, ecol = ncore - 1;
+  const int nt = (ncore + 15) >> 4, ntile = nt * (nt + 1) / 2;
+  int rc[MC_MAX_ROLES];
+#pragma unroll
+  for (int q = 0; q < MC_MAX_ROLES; ++q) rc[q] = -1;
+  rc[F2_ROLE_LM] = 6;   // the target pose columns 0..5 are not written here: they stay zero and are not flushed
+#pragma unroll
+  for (int j = 0; j < F2_MAX_CHAIN; ++j) {
+    if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j] >= 0) rc[F2_ROLE_CHAIN + 2 * j] = npo + 6 * j;
+    if (j < nch && f.rolecol[F2_ROLE_CHAIN + 2 * j + 1] >= 0) rc[F2_ROLE_CHAIN + 2 * j + 1] = npo + 3 + 6 * j;
+  }
+  if (f.rolecol[F2_ROLE_PROJ] >= 0) rc[F2_ROLE_PROJ] = npo + 6 * nch;
+  if (nd && f.rolecol[F2_ROLE_DIST] >= 0) rc[F2_ROLE_DIST] = npo + 6 * nch + pd;
+  if (tid < ecol) {
+    int role, d;
+    if (tid < 6) { role = -1; d = 0; }
+    else if (tid < npo) { role = F2_ROLE_LM; d = tid - 6; }
+    else if (tid < npo + 6 * nch) { const int j = (tid - npo) / 6, k = (tid - npo) - 6 * j; role = F2_ROLE_CHAIN + 2 * j + (k >= 3 ? 1 : 0); d = k >= 3 ? k - 3 : k; }
+    else if (tid < npo + 6 * nch + pd) { role = F2_ROLE_PROJ; d = tid - (npo + 6 * nch); }
+    else { role = F2_ROLE_DIST; d = tid - (npo + 6 * nch + pd); }
+    const int c0 = role >= 0 ? f.rolecol[role] : -1;
+    lcol[tid] = c0 >= 0 ? c0 + d : -1;
+  }
+  for (int i = tid; i < 256 * ld; i += 256) rows[i] = 0.0;   // columns of inactive roles are never written
+  for (int i = tid; i < ntile * 256; i += 256) gram[i] = 0.0;
+  __syncthreads();
+  const int r = tid & 1, lane = tid & 63, c16 = lane & 15, kr = lane >> 4;
+  f64x4 acc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int base = 0; base < gr.term_count; base += 128) {
+    const int k = base + (tid >> 1);
+    const int nrows = 2 * min(128, gr.term_count - base);
+    double* row = rows + tid * ld;
+    if (k < gr.term_count) {
+      const int term = b.lm_terms[gr.term_first + k];
+      const F2Common* cm = common + b.lm_obs_common[b.term_obs[term]];
+      double e[2];
+      TermOut out;
+      f2_term_cm(b, *cm, dc.x, term, dc.useM != 0, true, rc, row - r * ld, ld, e, out, 1 << r);
+      row[ecol] = e[r];
+    }
+    __syncthreads();
+    const int nsteps = (nrows + 3) >> 2;
+    for (int st = tid >> 6; st < nsteps; st += 4) {
+      const int rr = 4 * st + kr;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      if (rr < nrows) {
+        const double* rp = rows + rr * ld + c16;
+        if (c16 < ncore) v0 = rp[0];
+        if (16 + c16 < ncore) v1 = rp[16];
+        if (32 + c16 < ncore) v2 = rp[32];
+      }
+      // the landmark columns 6..8 lie in column tile 0: only the tile pairs (0, *) are needed
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc[0], 0, 0, 0);
+      if (nt > 1) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, acc[1], 0, 0, 0);
+      if (nt > 2) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v2, acc[3], 0, 0, 0);
+    }
+    __syncthreads();   // the row tile is rewritten by the next pass
+  }
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+    if (t < ntile && (t == 0 || t == 1 || t == 3)) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) atomicAdd(&gram[(t * 4 + rg) * 64 + lane], acc[t][rg]);
+    }
+  __syncthreads();
+  // the landmark's rows: (a in 6..8) x (bq in a..ecol)
+  for (int it = tid; it < 3 * (ncore - 6); it += 256) {
+    const int a = 6 + it % 3, bq = 6 + it / 3;
+    if (bq < a) continue;
+    const int ta = a >> 4, tb = bq >> 4, i = a & 15, jj = bq & 15;
+    const double m = gram[((tb * (tb + 1) / 2 + ta) * 4 + (i >> 2)) * 64 + (i & 3) * 16 + jj];
+    const int la = lcol[a];
+    if (la < 0) continue;
+    if (bq == ecol) { atomic_add_f64(dc.rhs + global_col(f, la), -m); continue; }
+    const int lb = lcol[bq];
+    if (lb < 0) continue;
+    atomic_add_f64(dc.Cx + entry_addr(f, dc.col_h, min(la, lb), max(la, lb)), m);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // F6 (initialisation problems: GyroscopeError over constants, ErrorTermTransformation).  Every term of a batch writes
@@ -2038,6 +2136,7 @@ struct MotionView {
   const double* Qband;   // n_coeff x S x (D x D), Q(i, i - d) row-major
   const int* slot;       // n_coeff x S: value offset of block (i-d, i) or -1
   int n_coeff, S, D, param_off, first_block, first_col;
+  int i_lo, i_hi;        // this rank's coefficients (Problem::motionRange; all of them without shards)
   int row;               // row of this term in e
   int term;              // global term index
 };
@@ -2045,9 +2144,9 @@ __global__ __launch_bounds__(256) void k_motion(const MotionView* __restrict__ v
   const MotionView m = views[blockIdx.y];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int D = m.D, S = m.S;
-  const int i = id / S, d = id - i * S;
+  const int i = m.i_lo + id / S, d = id % S;
   double part = 0.0;
-  if (i < m.n_coeff) {
+  if (i < m.i_hi) {
     const double* c = dc.x + m.param_off;
     double qc[6] = {0, 0, 0, 0, 0, 0};
     const int j = i - d, jj = i + d;
@@ -2236,7 +2335,7 @@ template <class T> struct DevBuf {
 // Per-batch device arrays (the SoA term records).
 struct DevBatch {
   DevBuf<double> t, y, p, sinv, S, meas, range, Qband;
-  DevBuf<int> obs_first, obs_q_off, obs_t_off, term_q_off, term_t_off, term_obs, slot, order, term_lo, term_nbuf;
+  DevBuf<int> obs_first, obs_q_off, obs_t_off, term_q_off, term_t_off, term_obs, slot, order, term_lo, term_nbuf, lm_terms, lm_obs_common, lm_slots;
 };
 
 // One kernel launch per term family: the batches (sensor streams) of a family share the launch through a device array
@@ -2249,6 +2348,10 @@ struct LaunchUnit {
   StreamDims dims{0, 0, 0, 0, 0, 0};
   int motion_blocks = 0;
   DevBuf<GroupRec> groups;
+  DevBuf<GroupRec> lm_groups;   // F2 with landmark design variables: work items of the landmark-major pass (k_static_lm)
+  int n_lm_groups = 0;
+  DevBuf<GroupRec> jt_groups;   // F2 with landmark design variables: the per-term groups the J^T kernel walks (groups = whole observations)
+  int n_jt_items = 0;
   DevBuf<ChunkRec> chunks;
   DevBuf<ReprojBatchView> rviews;
   DevBuf<StaticReprojBatchView> sviews;
@@ -2621,7 +2724,11 @@ void mc_context::uploadStructure() {
   std::vector<ImageRec> images, static_runs;
   // F2: observations per workgroup -- enough workgroups to fill the chip first, then longer runs (fewer camera-level flushes)
   int n_static_obs = 0;
-  for (const Batch& b : P.batches) if (b.kind == KIND_STATIC_REPROJ) n_static_obs += (int)b.my_groups.size();
+  for (const Batch& b : P.batches)
+    if (b.kind == KIND_STATIC_REPROJ)
+      n_static_obs += (int)(b.obs_groups.empty() || std::getenv("MC_LM_PER_TERM") ? b.my_groups.size() : b.my_obs_groups.size());
+  std::vector<GroupRec> jt_groups, lm_groups;
+  bool jt_groups_differ = false;
   const int static_run = std::min(8, std::max(1, n_static_obs / 1024));
   for (int l = 0; l < N_LAUNCH; ++l) lu[l] = LaunchUnit();
   int term_base = 0;
@@ -2658,7 +2765,23 @@ void mc_context::uploadStructure() {
     } else if (b.kind != KIND_MOTION) {
       double last_time = 0;
       bool first_of_batch = true;
-      for (GroupRec g : b.my_groups) {
+      // landmark batches: the evaluate / build kernel takes whole observations, the J^T kernel the per-term groups
+      // (MC_LM_PER_TERM=1: the round-2 shape, one group -- one workgroup pass -- per term over an active landmark; for comparison)
+      const bool lm_batch = b.kind == KIND_STATIC_REPROJ && !b.obs_groups.empty() && std::getenv("MC_LM_PER_TERM") == nullptr;
+      if (b.kind == KIND_STATIC_REPROJ) {
+        jt_groups_differ = jt_groups_differ || lm_batch;
+        for (GroupRec g : b.my_groups) if (g.term_count) { g.batch = view_index; jt_groups.push_back(g); }
+      }
+      if (lm_batch) {
+        // where the pre-pass record of an observation sits in the launch's group list, for the landmark-major pass
+        std::vector<int> at((int)b.obs_first.size() - 1, -1);
+        int pos = (int)groups[li].size();
+        for (const GroupRec& g : b.my_obs_groups) if (g.term_count) at[g.aux] = pos++;
+        d->lm_obs_common.upload(at);
+        d->lm_terms.upload(b.lm_terms);
+        for (GroupRec g : b.lm_groups) { g.batch = view_index; lm_groups.push_back(g); }
+      }
+      for (GroupRec g : (lm_batch ? b.my_obs_groups : b.my_groups)) {
         if (g.term_count == 0) continue;
         g.batch = view_index;
         if (b.kind == KIND_STATIC_REPROJ) {
@@ -2779,11 +2902,14 @@ void mc_context::uploadStructure() {
           if (b.term_dv_lm[k] >= 0) { lo[k] = P.dvs[b.term_dv_lm[k]].off; v.lm_scale = P.dvs[b.term_dv_lm[k]].scaling; }
         d->term_q_off.upload(lo);
         v.lm_off = d->term_q_off.p;
+        d->lm_slots.upload(b.lm_slots);
+        v.lm_slots = d->lm_slots.p;
+        v.lm_terms = d->lm_terms.p; v.lm_obs_common = d->lm_obs_common.p;
       }
       v.mest = b.mest; v.mest_a = b.mest_a; v.n_obs = (int)b.obs_first.size() - 1; v.n_terms = b.n_terms;
       v.row_base = b.row_base; v.term_base_global = term_base;
       sviews.push_back(v);
-    } else {  // KIND_MOTION: handled by rank 0 only (one whole-spline term)
+    } else {  // KIND_MOTION: one whole-spline term, its sums split over the ranks by coefficient
       const SplineRec& s = P.splines[b.spline];
       d->Qband.upload(b.Qband);
       int b0 = P.dvs[s.first_dv].block;
@@ -2800,8 +2926,9 @@ void mc_context::uploadStructure() {
       v.Qband = d->Qband.p; v.slot = d->slot.p; v.n_coeff = s.n_coeff; v.S = s.order; v.D = s.dim;
       v.param_off = s.param_off; v.first_block = b0; v.first_col = b0 >= 0 ? P.dvs[s.first_dv].col : -1;
       v.row = b.row_base; v.term = term_base;
+      P.motionRange(s, P.rank, v.i_lo, v.i_hi);
       mviews.push_back(v);
-      L.motion_blocks = std::max(L.motion_blocks, (s.n_coeff * s.order + 255) / 256);   // a lane per (coefficient, band offset)
+      L.motion_blocks = std::max(L.motion_blocks, ((v.i_hi - v.i_lo) * s.order + 255) / 256);   // a lane per (coefficient, band offset)
     }
     term_base += b.n_terms;
     db.push_back(std::move(d));
@@ -2812,9 +2939,9 @@ void mc_context::uploadStructure() {
     LaunchUnit& L = lu[l];
     L.jpart_base = n_jpart;
     if (l == LAUNCH_MOTION) {
-      L.n_items = P.rank == 0 ? (int)mviews.size() : 0;
+      L.n_items = (int)mviews.size();
+      L.motion_blocks = std::max(L.motion_blocks, 1);
       L.n_jpart = L.n_items * L.motion_blocks;
-      if (P.rank != 0) { L.flops_dense = L.flops_live = 0; }
     } else if (l == LAUNCH_IMU || l == LAUNCH_LIDAR || l == LAUNCH_IMU_SM) {
       L.chunks.upload(chunks[l]);
       L.n_items = (int)chunks[l].size();
@@ -2853,11 +2980,15 @@ void mc_context::uploadStructure() {
         if (L.f1_split) L.n_jpart = std::max(L.n_jpart, (L.n_passes + 3) / 4);
       } else if (l == LAUNCH_STATIC) {
         L.common2.alloc(groups[l].size());
+        if (jt_groups_differ) { L.jt_groups.upload(jt_groups); L.n_jt_items = (int)jt_groups.size(); }
+        if (!lm_groups.empty()) { L.lm_groups.upload(lm_groups); L.n_lm_groups = (int)lm_groups.size(); }
         L.images.upload(static_runs);
         L.n_images = (int)static_runs.size();
         L.n_jpart = L.n_images;
-        if (L.lds_bytes > 64 * 1024)
+        if (L.lds_bytes > 64 * 1024) {
           HIP_CHECK(hipFuncSetAttribute((const void*)k_static<true>, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+          HIP_CHECK(hipFuncSetAttribute((const void*)k_static_lm, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes));
+        }
       }
     }
     n_jpart += L.n_jpart;
@@ -2963,7 +3094,10 @@ void mc_context::launchAll(int build, int useM, double* dCx, double* dRhs, doubl
         break;
       case LAUNCH_STATIC:
         hipLaunchKernelGGL(k_static_common, dim3((L.n_items + 63) / 64), dim3(64), 0, st, L.sviews.p, x.p, L.groups.p, L.n_items, L.common2.p);
-        if (build) hipLaunchKernelGGL(k_static<true>, dim3(L.n_images), dim3(256), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.images.p, L.common2.p, L.static_ld, L.jpart_base);
+        if (build) {
+          hipLaunchKernelGGL(k_static<true>, dim3(L.n_images), dim3(256), L.lds_bytes, st, L.sviews.p, dc, L.groups.p, L.images.p, L.common2.p, L.static_ld, L.jpart_base);
+          if (L.n_lm_groups) hipLaunchKernelGGL(k_static_lm, dim3(L.n_lm_groups), dim3(256), L.lds_bytes, st, L.sviews.p, dc, L.lm_groups.p, L.common2.p, L.static_ld);
+        }
         else hipLaunchKernelGGL(k_static<false>, dim3(L.n_images), dim3(256), 0, st, L.sviews.p, dc, L.groups.p, L.images.p, L.common2.p, L.static_ld, L.jpart_base);
         break;
       case LAUNCH_IMU:
@@ -3041,7 +3175,8 @@ void mc_context::launchJt(int useM, double* dValues, hipStream_t st) {
   }
   if (lu[LAUNCH_STATIC].n_items) {
     LaunchUnit& L = lu[LAUNCH_STATIC];
-    hipLaunchKernelGGL(k_jt_static, dim3(L.n_items), dim3(64), 0, st, L.sviews.p, dc, L.groups.p, jt);
+    if (L.n_jt_items) hipLaunchKernelGGL(k_jt_static, dim3(L.n_jt_items), dim3(64), 0, st, L.sviews.p, dc, L.jt_groups.p, jt);
+    else hipLaunchKernelGGL(k_jt_static, dim3(L.n_items), dim3(64), 0, st, L.sviews.p, dc, L.groups.p, jt);
   }
   if (lu[LAUNCH_GYRO_PRIOR].n_items) {
     LaunchUnit& L = lu[LAUNCH_GYRO_PRIOR];

@@ -838,6 +838,9 @@ struct StaticReprojBatchView {
   const double* S = nullptr;   // optional general sqrtInvR, n x D x D row major (then sinv is not used)
   const int* lm_off = nullptr;   // optional, per term: parameter offset of the landmark (HomogeneousPoint), or -1
   double lm_scale = 1.0;
+  const int* lm_slots = nullptr;       // with lm_off, per term: Batch::lm_slots (4 ints: where its landmark x target-pose blocks sit)
+  const int* lm_terms = nullptr;       // terms listed by landmark (work items of the landmark-major pass)
+  const int* lm_obs_common = nullptr;  // per observation: index of its pre-pass record
   int mest; double mest_a;
   int n_obs, n_terms, row_base, term_base_global;
 };

@@ -194,3 +194,32 @@ def make_static_problem(cfg, make_api, noise=True):
     meas = synthesize_static(W, make_api, noise)
     spec, H = build_static_spec(W, static_initial(W), meas)
     return spec, H, W, meas
+
+
+def with_landmarks(spec, seed=2, inactive_every=7, constant_every=5, flip_w_every=0):
+    """a copy of a static spec whose target corners are HomogeneousPoint design variables shared by all cameras and views
+    (every `inactive_every`-th landmark inactive, every `constant_every`-th corner left a constant)"""
+    import copy
+    from . import spec as _S
+    rng = np.random.RandomState(seed)
+    sp = copy.deepcopy(spec)
+    pts = {}
+    for i, k, d in list(sp.batch_ops()):
+        if k != "static_reproj":
+            continue
+        handles = []
+        for row in d["p"]:
+            key = tuple(np.round(row, 9))
+            if key not in pts:
+                n = len(pts)
+                if constant_every and n % constant_every == constant_every - 1:
+                    pts[key] = None
+                else:
+                    ph = np.array([row[0], row[1], row[2], 1.0]) + np.r_[0.002 * rng.standard_normal(3), 0.0]
+                    if flip_w_every and n % flip_w_every == 0:
+                        ph = -ph                       # same point, w < 0
+                    pts[key] = sp.add_dv(_S.DV_HOMOGENEOUS_POINT, ph, not (inactive_every and n % inactive_every == 0), 1.0,
+                                         _S.HELPER_GROUP_ID)
+            handles.append(pts[key])
+        sp.set_landmarks(i, handles)
+    return sp

@@ -12,31 +12,7 @@ from probe_api import ProbeApi
 from test_oracle_identities import _fd_check
 
 
-def with_landmarks(spec, seed=2, inactive_every=7, constant_every=5, flip_w_every=0):
-    """a copy of a static spec whose target corners are HomogeneousPoint design variables shared by all cameras and views
-    (every `inactive_every`-th landmark inactive, every `constant_every`-th corner left a constant)"""
-    rng = np.random.RandomState(seed)
-    sp = copy.deepcopy(spec)
-    pts = {}
-    for i, k, d in list(sp.batch_ops()):
-        if k != "static_reproj":
-            continue
-        handles = []
-        for row in d["p"]:
-            key = tuple(np.round(row, 9))
-            if key not in pts:
-                n = len(pts)
-                if constant_every and n % constant_every == constant_every - 1:
-                    pts[key] = None
-                else:
-                    ph = np.array([row[0], row[1], row[2], 1.0]) + np.r_[0.002 * rng.standard_normal(3), 0.0]
-                    if flip_w_every and n % flip_w_every == 0:
-                        ph = -ph                       # same point, w < 0
-                    pts[key] = sp.add_dv(S.DV_HOMOGENEOUS_POINT, ph, not (inactive_every and n % inactive_every == 0), 1.0,
-                                         S.HELPER_GROUP_ID)
-            handles.append(pts[key])
-        sp.set_landmarks(i, handles)
-    return sp
+from multical_amd.synth_static import with_landmarks  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -159,3 +135,31 @@ def test_device_update_and_revert(lm_problem):
     Jo, _ = o2.evaluate_error(True)
     Jg, _ = g.evaluate_error(True)
     assert abs(Jg - Jo) <= 1e-9 * abs(Jo)
+
+
+@pytest.mark.gpu
+def test_device_parity_with_many_views_of_each_landmark():
+    """The landmark-major pass (k_static_lm) takes a landmark's terms of one camera in work items of <= 1024 terms and
+    passes of 128: 1 200 views of 5 corners put ~1 200 terms on every landmark, i.e. two work items and ten passes each;
+    the observation-major pass adds the landmark x target-pose blocks per term from the precomputed slots."""
+    from multical_amd import synth_static as SS
+    from multical_amd.backend import HipApi
+    cfg = SS.StaticConfig(n_cams=2, n_boards=1, n_views=1200, corner_stride=29, cam_models=[(0, 1), (2, 0)])
+    base = SS.make_static_problem(cfg, OracleApi)[0]
+    sp = SS.with_landmarks(base, inactive_every=4, constant_every=0)
+    o = OracleApi()
+    sp.emit(o)
+    o.finalize()
+    g = HipApi(0)
+    sp.emit(g)
+    g.finalize()
+    Cp, Ci = g.pattern()
+    Jo, eo = o.evaluate_error(True)
+    Cpo, Cio, Cx, rhs = o.build_system(True)
+    assert np.array_equal(Cp, Cpo) and np.array_equal(Ci, Cio)
+    Jg, eg = g.evaluate_error(True)
+    assert abs(Jg - Jo) <= 1e-9 * abs(Jo)
+    Cxg, rhsg = g.build_system(True)
+    assert np.abs(Cxg - Cx).max() <= 1e-9 * np.abs(Cx).max()
+    assert np.abs(rhsg - rhs).max() <= 1e-9 * np.abs(rhs).max()
+    assert np.array_equal(Cxg == 0.0, Cx == 0.0)

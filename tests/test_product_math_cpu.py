@@ -77,3 +77,39 @@ def test_cpu_optimised_baseline_equals_the_oracle(small_problem, small_oracle, t
     assert np.all(Cxp[Cx == 0.0] == 0.0)
     J2, _, _ = p.cpu_optimised(True, False, threads)
     assert abs(J2 - Jo) <= 1e-9 * Jo
+
+
+def test_motion_terms_are_split_over_the_shards_by_coefficient(small_problem):
+    """A BSplineMotionError term covers a whole spline; a rank takes the band columns, the rows of Q c and the cost share
+    of the coefficients in its window (Problem::motionRange).  Three shards of the small problem (motion priors on every
+    bias spline): the partial systems sum to the unsharded one, entries outside the shared set have one writer, and the
+    band of the motion terms does not end up in the shared set (it did while rank 0 took the whole term)."""
+    whole = ProbeApi()
+    small_problem["spec"].emit(whole)
+    whole.finalize()
+    J0, Cx0, rhs0 = whole.cpu_optimised(True, True, 2)
+    J = 0.0
+    Cx = np.zeros_like(Cx0)
+    rhs = np.zeros_like(rhs0)
+    writers = np.zeros(Cx0.size, int)
+    shared = None
+    for r in range(3):
+        p = ProbeApi()
+        p.set_shard(r, 3)
+        small_problem["spec"].emit(p)
+        p.finalize()
+        Jr, Cxr, rhsr = p.cpu_optimised(True, True, 2)
+        J += Jr
+        Cx += Cxr
+        rhs += rhsr
+        writers += Cxr != 0.0
+        s = p.shared_indices()
+        assert shared is None or np.array_equal(shared, s)      # the same list on every rank
+        shared = s
+    assert abs(J - J0) <= 1e-12 * J0
+    assert np.abs(Cx - Cx0).max() <= 1e-12 * np.abs(Cx0).max()
+    assert np.abs(rhs - rhs0).max() <= 1e-12 * np.abs(rhs0).max()
+    private = np.ones(Cx0.size, bool)
+    private[shared] = False
+    assert writers[private].max() <= 1
+    assert shared.size < 0.2 * Cx0.size, (shared.size, Cx0.size)
