@@ -7,6 +7,7 @@
 #include "../../multical_amd/csrc/mc_describe.hpp"
 #include "../../multical_amd/csrc/host/block_cholesky.hpp"
 #include "../../multical_amd/csrc/host/lm_core.hpp"
+#include "../../multical_amd/csrc/host/schur_plan.hpp"
 
 using namespace mc;
 
@@ -129,6 +130,51 @@ int probe_get_block_times(void* h, double* t) {
       if (b >= 0) t[b] = P.knots[s.knots_off + i + s.order];
     }
   return 0;
+}
+// spline of every coefficient block (-1: not a spline coefficient)
+static std::vector<int> blockSplines(const Problem& P) {
+  std::vector<int> sp(P.n_blocks, -1);
+  for (size_t s = 0; s < P.splines.size(); ++s)
+    for (int i = 0; i < P.splines[s].n_coeff; ++i) {
+      const int b = P.dvs[P.splines[s].first_dv + i].block;
+      if (b >= 0) sp[b] = (int)s;
+    }
+  return sp;
+}
+// The factorisation's GPU stage on the host: plan (host/schur_plan.hpp) + its reference executor + the host factorisation of
+// the reduced system.  Solves (H + shift I) x = g for the system in Cx (this problem's pattern; the plan is made on the
+// non-zero blocks of Cx_plan when that is given).  info: [plan ok, interiors,
+// r, reduced columns, reduced nnz, pairs that must stay zero]; returns 0 ok, 1 not positive definite, 2 structure grew,
+// 3 no plan for this problem.
+int probe_schur_solve(void* h, const double* Cx_plan, const double* Cx, const double* g, double shift, int parts, double* x, int* info) {
+  Probe* pr = (Probe*)h;
+  PR_TRY
+  Problem& P = pr->P;
+  std::vector<int> base(P.n_blocks + 1, 0);
+  for (int b = 0; b < P.n_blocks; ++b) base[b + 1] = base[b] + P.block_dim[b];
+  const std::vector<int> sp = blockSplines(P);
+  multical_amd::SchurPlan plan;
+  plan.build(P.j_cols, P.Cp.data(), P.Ci.data(), P.n_blocks, base.data(), sp.data(), Cx_plan ? Cx_plan : Cx, parts);
+  info[0] = plan.ok ? 1 : 0;
+  if (!plan.ok) { pr->err = plan.why; return 3; }
+  info[1] = (int)plan.parts.size(); info[2] = plan.r; info[3] = plan.R.n; info[4] = (int)plan.R.nnz(); info[5] = (int)plan.check.size();
+  std::vector<double> S, bS;
+  multical_amd::SchurPlan::HostWork wk;
+  if (!plan.eliminate(Cx, g, shift, S, bS, wk)) return 2;
+  std::vector<int> CpR, CiR;
+  plan.R.toScalar(CpR, CiR);
+  multical_amd::BlockSparseCholesky chol;
+  chol.analyze(plan.R.n, CpR.data(), CiR.data(), plan.R.nb, plan.R.base.data());
+  std::vector<double> when(P.n_blocks), whenR(plan.R.nb);
+  probe_get_block_times(h, when.data());
+  for (int i = 0; i < plan.R.nb; ++i) whenR[i] = when[plan.rblocks[i]];
+  chol.setBlockCoordinates(whenR.data(), 2);
+  if (!chol.factorize(S.data())) return 1;
+  std::vector<double> xR(plan.R.n);
+  chol.solve(bS.data(), xR.data());
+  plan.back(xR.data(), wk, x);
+  return 0;
+  PR_CATCH(pr, -1)
 }
 // number of groups kept by this rank / total (sharding checks)
 int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {

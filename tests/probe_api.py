@@ -156,6 +156,22 @@ class ProbeApi(object):
         self.L.probe_get_block_bases(self.h, _i(out))
         return out
 
+    def schur_solve(self, Cx, g, shift=0.0, parts=4, Cx_plan=None):
+        """(H + shift I) x = g through the interior elimination of host/schur_plan.hpp (reference executor) and the host
+        factorisation of the reduced system.  Returns (code, x, info)."""
+        x = np.zeros(self.j_cols)
+        info = np.zeros(6, np.int32)
+        Cx = np.ascontiguousarray(Cx, np.float64)
+        g = np.ascontiguousarray(g, np.float64)
+        self.L.probe_schur_solve.restype = C.c_int
+        if Cx_plan is not None:
+            Cx_plan = np.ascontiguousarray(Cx_plan, np.float64)
+        rc = self.L.probe_schur_solve(self.h, _d(Cx_plan) if Cx_plan is not None else None, _d(Cx), _d(g), C.c_double(shift),
+                                      C.c_int(parts), _d(x), _i(info))
+        if rc < 0:
+            self._chk(rc)
+        return rc, x, info
+
     def block_times(self):
         out = np.empty(self.n_blocks)
         self.L.probe_get_block_times(self.h, _d(out))
