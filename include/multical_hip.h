@@ -291,6 +291,9 @@ int mc_get_block_bases(const mc_context* ctx, int* base);
  * The coordinate along which the normal equations are banded; sorting by it eliminates a bias coefficient right after the
  * last pose coefficient it is coupled to.  mc_cholesky_set_block_coordinates uses it. */
 int mc_get_block_times(const mc_context* ctx, double* t);
+/* per block: index of the spline (order of the mc_add_spline calls) whose coefficient the block is, -1 for every other
+ * block (n_blocks entries).  The factorisation's GPU stage cuts the band of the spline with the most blocks. */
+int mc_get_block_splines(const mc_context* ctx, int* spline);
 
 /* sparse_block_matrix::LinearSolverCholmod<MatrixXd> (sparse_block_matrix/linear_solver_cholmod.h:55-112): analyze once
  * per structure, then factorize + solve per call.  The matrix is the upper-triangular scalar CCS that fillCCS emits;
@@ -319,6 +322,29 @@ int mc_cholesky_covariance_blocks(mc_cholesky* h, int n_pairs, const int* block_
                                   const long long* offsets, double* out);
 int mc_cholesky_stats(const mc_cholesky* h, int* n_dense_blocks, long long* nnz_factor, double* flops);
 int mc_cholesky_block_permutation(const mc_cholesky* h, int* perm /* n_blocks */);
+
+/* The factorisation's GPU stage (no counterpart in the reference, whose linear_solver_cholmod.h:70-112 factorises the whole
+ * matrix on one host core; INTEGRATION.md "Solving on the device").  The coefficients of the spline with the most blocks are
+ * cut into `parts` intervals (0: a default) with r separator blocks between neighbours; the interiors are eliminated on the
+ * device (banded Cholesky + dense products per interior), the reduced system -- separators, the other splines'
+ * coefficients, calibration parameters -- goes to the host factorisation above, the interiors are back-substituted on the
+ * device.  mc_schur_create plans on the pattern of ctx and the NON-ZERO blocks of d_Cx (device, nnz values, copied to the
+ * host once); it returns a handle even when the problem has no such band (then mc_schur_planned is 0 and
+ * mc_schur_last_error says why: the caller keeps mc_cholesky_*), NULL only on misuse.
+ * mc_schur_solve: (H + diag_shift I) x = rhs with H, rhs in device memory, x (JCols) to the host.  Returns 0; 1 = not
+ * positive definite; 2 = a block that was zero when the plan was made holds a value now (destroy, create again on the new
+ * values); -1 on errors.  The call synchronises the stream.
+ * mc_schur_info: counts = [interiors, r, block dim, columns, reduced columns, reduced nnz, watched zero blocks, largest
+ * boundary, largest interior, nnz of the reduced factor] (10 ints), seconds = [gather, eliminate, products, read-back, host
+ * factor + solve, back-substitution, planning, bytes of device work memory, flops of the reduced factorisation] (9 doubles)
+ * of the last solve. */
+typedef struct mc_schur mc_schur;
+mc_schur* mc_schur_create(mc_context* ctx, const double* d_Cx, int parts);
+void mc_schur_destroy(mc_schur* h);
+const char* mc_schur_last_error(const mc_schur* h);
+int mc_schur_planned(const mc_schur* h);
+int mc_schur_solve(mc_schur* h, const double* d_Cx, const double* d_rhs, double diag_shift, double* x_host, void* stream);
+int mc_schur_info(const mc_schur* h, int* counts, double* seconds);
 
 /* aslam::backend::Optimizer2Options (aslam_backend/include/aslam/backend/Optimizer2Options.hpp:9-42) with the two
  * shared_ptr members replaced by selectors; mc_optimizer_options_default fills the reference's defaults. */

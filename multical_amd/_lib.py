@@ -101,6 +101,13 @@ class SolutionReturnValue(C.Structure):
 SIGNATURES.update({
     "mc_get_block_bases": (C.c_int, [_ctx, _ip]),
     "mc_get_block_times": (C.c_int, [_ctx, _dp]),
+    "mc_get_block_splines": (C.c_int, [_ctx, _ip]),
+    "mc_schur_create": (C.c_void_p, [_ctx, C.c_void_p, C.c_int]),
+    "mc_schur_destroy": (None, [C.c_void_p]),
+    "mc_schur_last_error": (C.c_char_p, [C.c_void_p]),
+    "mc_schur_planned": (C.c_int, [C.c_void_p]),
+    "mc_schur_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, _dp, C.c_void_p]),
+    "mc_schur_info": (C.c_int, [C.c_void_p, _ip, _dp]),
     "mc_cholesky_create": (C.c_void_p, []),
     "mc_cholesky_destroy": (None, [C.c_void_p]),
     "mc_cholesky_last_error": (C.c_char_p, [C.c_void_p]),

@@ -514,6 +514,51 @@ class HostSparseCholesky(object):
         return x if np.all(np.isfinite(x)) else None
 
 
+class DeviceSchurSolver(object):
+    """The factorisation's GPU stage (multical_amd/csrc/mc_schur.hip through mc_schur_*): the interiors of the pose-spline
+    band are eliminated on the device, the reduced system is factorised on the host.  `planned` is False when the problem
+    has no band the kernels take (`why` says which); the caller keeps HostSparseCholesky then."""
+
+    def __init__(self, api, d_Cx, parts=0):
+        self.lib = api.lib
+        self.n = api.j_cols
+        self.h = self.lib.mc_schur_create(api.ctx, d_Cx, int(parts))
+        if not self.h:
+            raise BackendError("mc_schur_create failed")
+        self.planned = bool(self.lib.mc_schur_planned(self.h))
+        self.why = "" if self.planned else self.lib.mc_schur_last_error(self.h).decode()
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.mc_schur_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def solve(self, d_Cx, d_rhs, diag_shift=0.0, stream=None):
+        """(H + diag_shift I) x = rhs; returns (code, x): 0 ok, 1 not positive definite, 2 plan again"""
+        x = np.zeros(self.n)
+        rc = self.lib.mc_schur_solve(self.h, d_Cx, d_rhs, float(diag_shift), _dp(x), stream)
+        if rc < 0:
+            raise BackendError(self.lib.mc_schur_last_error(self.h).decode())
+        return rc, x
+
+    def info(self):
+        c = np.zeros(10, np.int32)
+        t = np.zeros(9)
+        if self.lib.mc_schur_info(self.h, _ip(c), _dp(t)) != 0:
+            return None
+        keys = ("interiors", "r", "block_dim", "columns", "reduced_columns", "reduced_nnz", "watched_zero_blocks", "largest_boundary",
+                "largest_interior", "reduced_factor_nnz")
+        out = dict(zip(keys, [int(v) for v in c]))
+        out["seconds"] = dict(zip(("gather", "eliminate", "products", "read_back", "host_reduced", "back_substitution"), [float(v) for v in t[:6]]))
+        out["plan_seconds"] = float(t[6])
+        out["work_bytes"] = float(t[7])
+        out["reduced_factor_flops"] = float(t[8])
+        return out
+
+
 class HipBlockCholeskyLinearSystemSolver(object):
     """LinearSystemSolver backend: same virtual surface as BlockCholeskyLinearSystemSolver."""
 

@@ -10,9 +10,12 @@
 //   * the decision about a trial falls in two parts, like the reference's: accept / reject from the cost alone, and -- one
 //     iteration later, from the gain ratio -- whether the system linearised at the accepted state replaces the current one
 //     (ADOPT: swap of the two device buffers + one device-to-host copy) or the old system is kept with a larger damping.
-//   * the factorisation works on a pinned host image of the adopted system, whose diagonal keeps the reference's
-//     damping residue (augmented by lambda^2, relieved by lambda: BlockCholeskyLinearSystemSolver.cpp:76-98) until the next
-//     adoption overwrites it.
+//   * the factorisation keeps the reference's damping residue on the diagonal of the adopted system (augmented by lambda^2,
+//     relieved by lambda: BlockCholeskyLinearSystemSolver.cpp:76-98) until the next adoption.  Two ways to factorise:
+//     the GPU stage (mc_schur.hip: interiors of the pose-spline band eliminated on the device from the adopted device system,
+//     the reduced system on the host; the residue is one scalar added to every diagonal entry) when the problem has such a
+//     band, else -- or with MC_GPU_SOLVE=0, or with shards -- the host factorisation on a pinned host image of the system,
+//     whose diagonal carries the residue.
 //
 // Only the ARITHMETIC of the damping schedule (Nielsen's rule with gamma = 3, beta = 2, p = 3, mu0 = 2), of the gain ratio and
 // of the stopping rule is shared with the reference -- the iterates must match it to 1e-7.  Policies: Levenberg-Marquardt
@@ -29,6 +32,7 @@
 
 #include "../hip_linear_system_solver.hpp"
 #include "lm_core.hpp"
+#include "schur_device.hpp"
 
 namespace multical_amd {
 
@@ -59,7 +63,10 @@ struct ShardHooks {
 // and solves, the step is broadcast, and every rank applies the same update to its replica of the state.
 class FusedBlockEquations : public NormalEquations {
  public:
-  explicit FusedBlockEquations(mc_context* ctx, ShardHooks hooks = ShardHooks()) : ctx_(ctx), hooks_(hooks) {}
+  explicit FusedBlockEquations(mc_context* ctx, ShardHooks hooks = ShardHooks()) : ctx_(ctx), hooks_(hooks) {
+    const char* v = std::getenv("MC_GPU_SOLVE");
+    gpuSolve_ = !hooks_.active() && !(v && v[0] == '0');
+  }
   ~FusedBlockEquations() override {
     for (int k = 0; k < 2; ++k) { if (dH_[k]) (void)hipFree(dH_[k]); if (dG_[k]) (void)hipFree(dG_[k]); }
     if (dCost_) (void)hipFree(dCost_);
@@ -75,11 +82,10 @@ class FusedBlockEquations : public NormalEquations {
     ok(mc_get_pattern(ctx_, colEnd_.data(), rowIdx.data()));
     ok(mc_get_block_bases(ctx_, base.data()));
     chol_.analyze(n_, colEnd_.data(), rowIdx.data(), blocks, base.data());
-    {
-      std::vector<double> when(blocks);
-      ok(mc_get_block_times(ctx_, when.data()));
-      chol_.setBlockCoordinates(when.data(), hostCholeskyThreads());   // time-axis dissection: one thread per part
-    }
+    rowIdx_.swap(rowIdx); base_.swap(base);
+    when_.assign(blocks, 0.0);
+    ok(mc_get_block_times(ctx_, when_.data()));
+    chol_.setBlockCoordinates(when_.data(), hostCholeskyThreads());   // time-axis dissection: one thread per part
     for (int k = 0; k < 2; ++k) {
       detail::hipOk(hipMalloc((void**)&dH_[k], sizeof(double) * (size_t)nnz_), "hipMalloc(system values)");
       detail::hipOk(hipMalloc((void**)&dG_[k], sizeof(double) * (size_t)n_), "hipMalloc(gradient)");
@@ -127,13 +133,34 @@ class FusedBlockEquations : public NormalEquations {
       if (hooks_.allreduce(hooks_.user, dH_[cur_], nnz_) != 0 || hooks_.allreduce(hooks_.user, dG_[cur_], n_) != 0)
         throw Exception("sharded minimiser: all-reduce of the normal equations failed");
     }
-    detail::hipOk(hipMemcpy(hH_, dH_[cur_], sizeof(double) * (size_t)nnz_, hipMemcpyDeviceToHost), "system read-back");
+    shift_ = 0.0;
+    hostImage_ = false;
+    if (!gpuSolve_) readBackSystem();     // the GPU stage works on the device system: 8 nnz bytes stay where they are
     detail::hipOk(hipMemcpy(g_.data(), dG_[cur_], sizeof(double) * (size_t)n_, hipMemcpyDeviceToHost), "gradient read-back");
   }
   bool step(double damping, std::vector<double>& dx) override {
+    dx.assign(n_, 0.0);
+    if (gpuSolve_) {
+      if (damped_) shift_ += damping * damping;
+      int rc = planGpuStage() ? schur_->solve(dH_[cur_], dG_[cur_], shift_, dx.data(), nullptr) : 3;
+      if (rc == 2) {                       // a block that was zero when the plan was made holds a value now
+        schur_.reset();
+        rc = planGpuStage() ? schur_->solve(dH_[cur_], dG_[cur_], shift_, dx.data(), nullptr) : 3;
+      }
+      if (rc == 0 || rc == 1) {
+        bool good = rc == 0;
+        if (good) for (double v : dx) if (!std::isfinite(v)) { good = false; break; }
+        if (damped_) shift_ -= damping;    // the reference relieves the diagonal by the damping, not by its square
+        return good;
+      }
+      // no band the kernels take (or it outgrew them): the host factorisation from here on, on an image with the residue so far
+      gpuSolve_ = false;
+      if (damped_) shift_ -= damping * damping;
+      if (!hostImage_) readBackSystem();
+      for (int c = 0; c < n_; ++c) hH_[colEnd_[c + 1] - 1] += shift_;
+    }
     // the diagonal entry of column c is the last one of the column (upper triangle in compressed columns)
     if (damped_) for (int c = 0; c < n_; ++c) hH_[colEnd_[c + 1] - 1] += damping * damping;
-    dx.assign(n_, 0.0);
     bool good = true;
     if (!hooks_.active() || hooks_.rank == 0) {   // with shards: one factorisation, on rank 0
       good = chol_.factorize(hH_);
@@ -155,10 +182,43 @@ class FusedBlockEquations : public NormalEquations {
   const std::vector<double>& gradient() const override { return g_; }
   void applyUpdate(const std::vector<double>& dx) override { ok(mc_apply_update(ctx_, dx.data())); }
   void revertUpdate() override { ok(mc_revert_update(ctx_)); }
-  void factorStats(double& nnz, double& flops) override { nnz = (double)chol_.stats().nnz_factor; flops = chol_.stats().flops; }
+  void factorStats(double& nnz, double& flops) override {
+    if (gpuSolve_ && schur_ && schur_->planned()) { nnz = (double)schur_->info().reduced_factor_nnz; flops = schur_->info().reduced_factor_flops; return; }
+    nnz = (double)chol_.stats().nnz_factor; flops = chol_.stats().flops;
+  }
+  bool usesGpuStage() const { return gpuSolve_ && schur_ && schur_->planned(); }
 
  private:
   void ok(int rc) const { if (rc < 0) throw Exception(mc_last_error(ctx_)); }
+  void readBackSystem() {
+    detail::hipOk(hipMemcpy(hH_, dH_[cur_], sizeof(double) * (size_t)nnz_, hipMemcpyDeviceToHost), "system read-back");
+    hostImage_ = true;
+  }
+  // plans the GPU stage on the non-zero blocks of the adopted system (once, and again when the structure grew)
+  bool planGpuStage() {
+    if (schur_ && schur_->planned()) return true;
+    if (schurFailed_) return false;
+    if (!hostImage_) readBackSystem();
+    std::vector<int> spl(base_.size() - 1);
+    ok(mc_get_block_splines(ctx_, spl.data()));
+    int band = 0;
+    {
+      std::vector<int> count;
+      for (int s : spl) if (s >= 0) { if ((int)count.size() <= s) count.resize(s + 1, 0); band = std::max(band, ++count[s]); }
+    }
+    int device = 0;
+    detail::hipOk(hipGetDevice(&device), "hipGetDevice");
+    schur_.reset(new SchurSolver());
+    try {
+      if (schur_->plan(device, n_, colEnd_.data(), rowIdx_.data(), (int)base_.size() - 1, base_.data(), spl.data(), when_.data(), hH_, schurPartsFor(band),
+                       hostCholeskyThreads()))
+        return true;
+    } catch (const std::exception& e) {
+      throw Exception(std::string("factorisation, GPU stage: ") + e.what());
+    }
+    schurFailed_ = true;
+    return false;
+  }
   mc_context* ctx_;
   ShardHooks hooks_;
   bool damped_ = true, trialPending_ = false;
@@ -167,9 +227,13 @@ class FusedBlockEquations : public NormalEquations {
   double* dG_[2] = {nullptr, nullptr};
   double* dCost_ = nullptr;
   double* hH_ = nullptr;
-  std::vector<int> colEnd_;
-  std::vector<double> g_;
+  std::vector<int> colEnd_, rowIdx_, base_;
+  std::vector<double> g_, when_;
   BlockSparseCholesky chol_;
+  // the GPU stage of the factorisation
+  bool gpuSolve_ = false, schurFailed_ = false, hostImage_ = false;
+  double shift_ = 0.0;          // the damping residue on the diagonal (the same for every column)
+  std::unique_ptr<SchurSolver> schur_;
 };
 
 // The second backend (J^T in compressed columns): nothing to speculate with -- the trial is the residual pass and the

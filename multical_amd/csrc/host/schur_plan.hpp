@@ -102,7 +102,8 @@ struct BlockPattern {
 };
 
 struct SchurPlan {
-  enum { MAX_BW = 36 };     // scalar width of the band window the elimination kernel keeps in LDS: d (r + 1)
+  enum { MAX_BW = 36,       // scalar width of the band window the elimination kernel keeps in LDS: d (r + 1)
+         MAX_DIM = 16 };    // widest design-variable block the gather kernels take (a lane per column of a block pair)
   bool ok = false;
   std::string why;          // when !ok
   BlockPattern A;           // the assembled matrix
@@ -159,6 +160,7 @@ struct SchurPlan {
   void build(int n, const int* Cp, const int* Ci, int nb, const int* base, const int* spline_of, const double* Cx, int want_parts) {
     ok = false; why.clear();
     A.fromScalar(n, Cp, Ci, nb, base);
+    for (int b = 0; b < nb; ++b) if (A.dim(b) > MAX_DIM) { why = "a design-variable block wider than 16 columns"; return; }
     // ---- the band spline: the one with the most blocks; they must be consecutive and of one dimension
     int best = -1, bestCount = 0;
     {
@@ -197,21 +199,13 @@ struct SchurPlan {
         at += m + r;
       }
     }
-    // ---- boundaries (numerical pattern), band pairs, pairs that must stay zero
+    // ---- boundaries: the blocks that hold a non-zero value against an interior block
     std::vector<std::vector<int>> Bset(P);
-    band.clear(); check.clear();
     for (int cb = 0; cb < nb; ++cb)
       for (int k = A.colPtr[cb]; k < A.colPtr[cb + 1]; ++k) {
         const int rb = A.rowBlk[k];
         const int pr = partOf[rb], pc = partOf[cb];
-        if (pr < 0 && pc < 0) continue;
-        const bool sameBand = pr >= 0 && pr == pc;
-        if (!nz[k] || (sameBand && cb - rb > r)) {
-          if (!nz[k]) check.push_back(CheckPair{A.first(k, cb), A.h[cb], A.dim(rb), A.dim(cb), rb == cb ? 1 : 0});
-          else { why = "interior band wider than r"; return; }
-          continue;
-        }
-        if (sameBand) { band.push_back(BandPair{A.first(k, cb), A.h[cb], pr, cb - parts[pr].i0, cb - rb, 0}); continue; }
+        if (!nz[k] || (pr < 0 && pc < 0) || (pr >= 0 && pr == pc)) continue;
         if (pr >= 0 && pc >= 0) { why = "two interiors are coupled"; return; }
         if (pr >= 0) Bset[pr].push_back(cb); else Bset[pc].push_back(rb);
       }
@@ -229,18 +223,32 @@ struct SchurPlan {
       pt.bandOff = bandTotal; bandTotal += (long long)pt.nI * bw;
       maxNB = std::max(maxNB, pt.nB); maxNI = std::max(maxNI, pt.nI);
     }
-    // ---- W pairs
-    wpairs.clear();
+    // ---- every stored pair that touches an interior block: inside the band (distance <= r) and against a block of the
+    // boundary it is gathered whether it holds a value now or not -- a live window that moves by a segment brings values to
+    // such pairs all the time, and they cost nothing here; any other pair must stay zero and is watched
+    band.clear(); check.clear(); wpairs.clear();
     for (int cb = 0; cb < nb; ++cb)
       for (int k = A.colPtr[cb]; k < A.colPtr[cb + 1]; ++k) {
         const int rb = A.rowBlk[k];
         const int pr = partOf[rb], pc = partOf[cb];
-        if (!nz[k] || (pr < 0) == (pc < 0)) continue;
-        const int p = pr >= 0 ? pr : pc, ib = pr >= 0 ? rb : cb, ob = pr >= 0 ? cb : rb;
-        const Part& pt = parts[p];
-        const int lb = (int)(std::lower_bound(pt.B.begin(), pt.B.end(), ob) - pt.B.begin());
-        // byRow = 1: the interior block is the ROW block of the stored pair (element (rr, cc): interior component rr, boundary component cc)
-        wpairs.push_back(WPair{A.first(k, cb), A.h[cb], p, pt.Boff[lb], (ib - pt.i0) * d, A.dim(rb), A.dim(cb), pr >= 0 ? 1 : 0});
+        if (pr < 0 && pc < 0) continue;
+        bool taken = false;
+        if (pr >= 0 && pr == pc) {
+          if (cb - rb <= r) { band.push_back(BandPair{A.first(k, cb), A.h[cb], pr, cb - parts[pr].i0, cb - rb, 0}); taken = true; }
+        } else if ((pr < 0) != (pc < 0)) {
+          const int p = pr >= 0 ? pr : pc, ib = pr >= 0 ? rb : cb, ob = pr >= 0 ? cb : rb;
+          const Part& pt = parts[p];
+          const auto it = std::lower_bound(pt.B.begin(), pt.B.end(), ob);
+          if (it != pt.B.end() && *it == ob) {
+            const int lb = (int)(it - pt.B.begin());
+            // byRow = 1: the interior block is the ROW block of the stored pair (element (rr, cc): interior component rr, boundary component cc)
+            wpairs.push_back(WPair{A.first(k, cb), A.h[cb], p, pt.Boff[lb], (ib - pt.i0) * d, A.dim(rb), A.dim(cb), pr >= 0 ? 1 : 0});
+            taken = true;
+          }
+        }
+        if (taken) continue;
+        if (nz[k]) { why = "a non-zero block pair outside the planned structure"; return; }
+        check.push_back(CheckPair{A.first(k, cb), A.h[cb], A.dim(rb), A.dim(cb), rb == cb ? 1 : 0});
       }
     // ---- reduced system: every block that is not interior, in the original order
     rmap.assign(nb, -1); rblocks.clear();

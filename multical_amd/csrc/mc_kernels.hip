@@ -3384,6 +3384,17 @@ int mc_get_block_times(const mc_context* ctx, double* t) {
     }
   return 0;
 }
+int mc_get_block_splines(const mc_context* ctx, int* spline) {
+  if (!ctx->P.finalized || !spline) return -1;
+  const Problem& P = ctx->P;
+  for (int b = 0; b < P.n_blocks; ++b) spline[b] = -1;
+  for (size_t s = 0; s < P.splines.size(); ++s)
+    for (int i = 0; i < P.splines[s].n_coeff; ++i) {
+      const int b = P.dvs[P.splines[s].first_dv + i].block;
+      if (b >= 0) spline[b] = (int)s;
+    }
+  return 0;
+}
 int mc_get_pattern(const mc_context* ctx, int* Cp, int* Ci) {
   if (!ctx->P.finalized) return -1;
   if (Cp) std::memcpy(Cp, ctx->P.Cp.data(), sizeof(int) * ctx->P.Cp.size());
