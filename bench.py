@@ -344,6 +344,30 @@ def main():
         out["config"]["host_cholesky_analyze_s"] = round(t_analyze, 3)
         out["config"]["host_cholesky_ok"] = bool(ok)
         out["config"]["host_cholesky"] = s._host.stats()
+        # the same solve through the factorisation's GPU stage (mc_schur.hip: interiors of the pose-spline band eliminated on
+        # the device from the device system, reduced system on the host) -- what mc_optimize runs by default; outside `value`
+        from multical_amd.backend import DeviceSchurSolver
+        st = torch.cuda.current_stream().cuda_stream
+        api.evaluate_error(True)
+        api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), st)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        gs = DeviceSchurSolver(api, dCx.data_ptr())
+        t_plan = time.perf_counter() - ts
+        if gs.planned:
+            t_dev = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                rc, x_dev = gs.solve(dCx.data_ptr(), drhs.data_ptr(), 100.0, st)
+                t_dev.append(time.perf_counter() - ts)
+            info = gs.info()
+            out["config"]["solve_s"] = round(min(t_dev[1:]), 4)
+            out["config"]["solve"] = dict(stage="interiors on the GPU, reduced system on the host", ok=bool(rc == 0), plan_s=round(t_plan, 3),
+                                          first_call_s=round(t_dev[0], 3), interiors=info["interiors"], reduced_columns=info["reduced_columns"],
+                                          reduced_nnz=info["reduced_nnz"], phases_ms={k: round(v * 1e3, 3) for k, v in info["seconds"].items()})
+        else:
+            out["config"]["solve"] = dict(stage="host only: " + gs.why)
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"], out["cpu_optimised"] = cpu_baseline(args, synth, spec)

@@ -305,14 +305,19 @@ __global__ __launch_bounds__(256) void k_schur_back(const PartDev* __restrict__ 
   __syncthreads();
   if (wave != 0) return;
   double xk = 0.0;                         // lane l holds x(c + 1 + l)
+  // the loads of step c - 1 (its row of U, its diagonal, its t) are issued before the reduction of step c: they do not depend on it
+  auto rowU = [&](int c) { const int k = c + 1 + lane; return (c >= 0 && lane < bw - 1 && k < nI) ? Ab[(long long)k * bw + (k - c)] : 0.0; };
+  double u = rowU(nI - 1), dg = Ab[(long long)(nI - 1) * bw], t = x[pt.c00 + nI - 1];
   for (int c = nI - 1; c >= 0; --c) {
-    const int k = c + 1 + lane;
-    const double u = (lane < bw - 1 && k < nI) ? Ab[(long long)k * bw + (k - c)] : 0.0;
+    const double un = rowU(c - 1);
+    const double dn = c > 0 ? Ab[(long long)(c - 1) * bw] : 1.0;
+    const double tn = c > 0 ? x[pt.c00 + c - 1] : 0.0;
     const double s = waveSum(u * xk);
-    const double xc = (x[pt.c00 + c] - s) / Ab[(long long)c * bw];
+    const double xc = (t - s) / dg;
     const double up = __shfl_up(xk, 1);
     xk = lane == 0 ? xc : up;
     if (lane == 0) x[pt.c00 + c] = xc;
+    u = un; dg = dn; t = tn;
   }
 }
 
@@ -411,6 +416,9 @@ bool SchurSolver::plan(int device, int n, const int* Cp, const int* Ci, int n_bl
   if (when) {
     std::vector<double> whenR(pl.R.nb);
     for (int i = 0; i < pl.R.nb; ++i) whenR[i] = when[pl.rblocks[i]];
+    // the reduced system is a sixth of the assembled one: MC_SCHUR_HOST_THREADS overrides the host factorisation's thread
+    // count for it (more parts mean a larger serial top)
+    if (const char* v = std::getenv("MC_SCHUR_HOST_THREADS")) host_threads = std::max(1, std::atoi(v));
     m.chol.setBlockCoordinates(whenR.data(), host_threads);
   }
   Info& in = m.info;
