@@ -65,7 +65,9 @@ class FusedBlockEquations : public NormalEquations {
  public:
   explicit FusedBlockEquations(mc_context* ctx, ShardHooks hooks = ShardHooks()) : ctx_(ctx), hooks_(hooks) {
     const char* v = std::getenv("MC_GPU_SOLVE");
-    gpuSolve_ = !hooks_.active() && !(v && v[0] == '0');
+    // with shards the summed system is on every rank's device; rank 0 solves (fp64 atomics make the stage's result depend on
+    // the order of additions in the last bits, and the ranks' states must stay bit-identical: one solve, then the broadcast)
+    gpuSolve_ = !(v && v[0] == '0') && (!hooks_.active() || hooks_.rank == 0);
   }
   ~FusedBlockEquations() override {
     for (int k = 0; k < 2; ++k) { if (dH_[k]) (void)hipFree(dH_[k]); if (dG_[k]) (void)hipFree(dG_[k]); }
@@ -135,7 +137,8 @@ class FusedBlockEquations : public NormalEquations {
     }
     shift_ = 0.0;
     hostImage_ = false;
-    if (!gpuSolve_) readBackSystem();     // the GPU stage works on the device system: 8 nnz bytes stay where they are
+    // the GPU stage works on the device system (8 nnz bytes stay where they are); with shards only rank 0 factorises at all
+    if (!gpuSolve_ && (!hooks_.active() || hooks_.rank == 0)) readBackSystem();
     detail::hipOk(hipMemcpy(g_.data(), dG_[cur_], sizeof(double) * (size_t)n_, hipMemcpyDeviceToHost), "gradient read-back");
   }
   bool step(double damping, std::vector<double>& dx) override {
@@ -151,7 +154,7 @@ class FusedBlockEquations : public NormalEquations {
         bool good = rc == 0;
         if (good) for (double v : dx) if (!std::isfinite(v)) { good = false; break; }
         if (damped_) shift_ -= damping;    // the reference relieves the diagonal by the damping, not by its square
-        return good;
+        return shareStep(good, dx);
       }
       // no band the kernels take (or it outgrew them): the host factorisation from here on, on an image with the residue so far
       gpuSolve_ = false;
@@ -169,15 +172,9 @@ class FusedBlockEquations : public NormalEquations {
         for (double v : dx) if (!std::isfinite(v)) { good = false; break; }
       }
     }
-    if (hooks_.active()) {
-      dx.push_back(good ? 1.0 : 0.0);
-      if (hooks_.broadcast(hooks_.user, dx.data(), (long long)dx.size(), 0) != 0) throw Exception("sharded minimiser: broadcast of the step failed");
-      good = dx.back() != 0.0;
-      dx.pop_back();
-    }
     // the reference relieves the diagonal by the damping, not by its square; the difference stays until the next adoption
     if (damped_) for (int c = 0; c < n_; ++c) hH_[colEnd_[c + 1] - 1] -= damping;
-    return good;
+    return shareStep(good, dx);
   }
   const std::vector<double>& gradient() const override { return g_; }
   void applyUpdate(const std::vector<double>& dx) override { ok(mc_apply_update(ctx_, dx.data())); }
@@ -190,6 +187,15 @@ class FusedBlockEquations : public NormalEquations {
 
  private:
   void ok(int rc) const { if (rc < 0) throw Exception(mc_last_error(ctx_)); }
+  // with shards: rank 0's step (and whether it has one) goes to every rank
+  bool shareStep(bool good, std::vector<double>& dx) {
+    if (!hooks_.active()) return good;
+    dx.push_back(good ? 1.0 : 0.0);
+    if (hooks_.broadcast(hooks_.user, dx.data(), (long long)dx.size(), 0) != 0) throw Exception("sharded minimiser: broadcast of the step failed");
+    good = dx.back() != 0.0;
+    dx.pop_back();
+    return good;
+  }
   void readBackSystem() {
     detail::hipOk(hipMemcpy(hH_, dH_[cur_], sizeof(double) * (size_t)nnz_, hipMemcpyDeviceToHost), "system read-back");
     hostImage_ = true;
