@@ -173,15 +173,29 @@ class BlockSparseCholesky {
     }
     if (!ok) return false;
     const auto t3 = now();
+    // the parts' images of the top's panels are summed by all threads (a streaming pass over up to P copies of the top:
+    // on one thread it took as long as the top's factorisation itself), the panels shared out like their preparation
+    {
+      auto sum = [&](int t) {
+        for (int j = top_start_panel_ + t; j < np_; j += P) {
+          double* Pj = Lx_.data() + valptr_[j];
+          const size_t len = (size_t)m_[j] * dim_[j];
+          for (int u = 0; u < P; ++u) {
+            if (!work[u].hit[j]) continue;
+            const double* add = work[u].top.data() + (valptr_[j] - top0);
+            for (size_t i = 0; i < len; ++i) Pj[i] += add[i];
+          }
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < P; ++t) th.emplace_back(sum, t);
+      sum(0);
+      for (std::thread& x : th) x.join();
+    }
+    const auto t3b = now();
     Work ws(np_, nb_, 0);
     for (int j = top_start_panel_; j < np_; ++j) {
       double* Pj = Lx_.data() + valptr_[j];
-      const size_t len = (size_t)m_[j] * dim_[j];
-      for (int t = 0; t < P; ++t) {
-        if (!work[t].hit[j]) continue;
-        const double* add = work[t].top.data() + (valptr_[j] - top0);
-        for (size_t i = 0; i < len; ++i) Pj[i] += add[i];
-      }
       applyUpdates(j, Pj, ws);
       if (!factorPanel(Pj, dim_[j], m_[j])) return false;
       link(j, ws.head);
@@ -192,8 +206,8 @@ class BlockSparseCholesky {
       std::fprintf(stderr, "\n");
     }
     if (timing)
-      std::fprintf(stderr, "cholesky: %d blocks in %d panels, symbolic %.1f ms, value check %.1f ms, %d parts %.1f ms, top (%d panels, %d columns) %.1f ms\n", nb_, np_, ms(t0, t1),
-                   ms(t1, t2), P, ms(t2, t3), np_ - top_start_panel_, n_ - pbase_[top_start_panel_], ms(t3, now()));
+      std::fprintf(stderr, "cholesky: %d blocks in %d panels, symbolic %.1f ms, value check %.1f ms, %d parts %.1f ms, images summed %.1f ms, top (%d panels, %d columns) %.1f ms\n", nb_, np_, ms(t0, t1),
+                   ms(t1, t2), P, ms(t2, t3), ms(t3, t3b), np_ - top_start_panel_, n_ - pbase_[top_start_panel_], ms(t3b, now()));
     factored_ = true;
     return true;
   }

@@ -441,7 +441,13 @@ int SchurSolver::solve(const double* d_Cx, const double* d_g, double shift, doub
   const int P = (int)pl.parts.size();
   const size_t nnzR = (size_t)pl.R.nnz();
   double t0 = nowSeconds();
-  auto lap = [&](int slot) { hipDo(hipStreamSynchronize(st), "hipStreamSynchronize"); const double t = nowSeconds(); m.info.seconds[slot] = t - t0; t0 = t; };
+  auto lap = [&](int slot) {
+    hipDo(hipGetLastError(), "kernel launch (factorisation, GPU stage)");
+    hipDo(hipStreamSynchronize(st), "hipStreamSynchronize");
+    const double t = nowSeconds();
+    m.info.seconds[slot] = t - t0; t0 = t;
+  };
+  for (double& v : m.info.seconds) v = 0.0;
   auto blocks8 = [](size_t pairs) { return dim3((unsigned)((pairs * 16 + 255) / 256)); };
   hipDo(hipMemsetAsync(m.flag.p, 0, 2 * sizeof(int), st), "hipMemsetAsync");
   hipDo(hipMemsetAsync(m.S.p, 0, sizeof(double) * nnzR, st), "hipMemsetAsync");
@@ -502,8 +508,12 @@ mc_schur* mc_schur_create(mc_context* ctx, const double* d_Cx, int parts) {
     std::vector<double> when(nb), Cx(nnz);
     if (mc_get_pattern(ctx, Cp.data(), Ci.data()) < 0 || mc_get_block_bases(ctx, base.data()) < 0 || mc_get_block_times(ctx, when.data()) < 0 ||
         mc_get_block_splines(ctx, spl.data()) < 0) return nullptr;
+    // the device that holds the system (the context's): the plan's tables and work arrays go there
     int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_Cx) == hipSuccess) device = attr.device;
+    else { (void)hipGetLastError(); if (hipGetDevice(&device) != hipSuccess) return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
     if (hipMemcpy(Cx.data(), d_Cx, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
     h = new mc_schur();
     if (parts <= 0) {
