@@ -1,0 +1,372 @@
+"""Whole error terms from first principles at 40 digits (mpmath): the LiDAR point-to-plane term, the gyroscope and the
+accelerometer term of the calibrated IMU model and of the scale-misalignment / size-effect models -- residual AND every
+Jacobian column, the latter by 40-digit differentiation
+of the residual along each design variable's own update rule (additive; RotationQuaternion: updateQuat; EuclideanDirection:
+C <- C * ypr(0, dp0, dp1)^T; the time offset moves the spline's evaluation time).  Nothing of the oracle's or the product's
+chain rule is used: the residuals are written down from the reference's expression trees
+(multical/.../sensors_and_targets.py:274-305 LiDAR, :1152-1170 accelerometer, :1198-1212 gyroscope, :1455-1550 and :1609-1665
+the scale-misalignment and size-effect models; MatrixBasicDv: the k-th flagged entry of the row-major update pattern moves) with
+the primitives
+that tests/test_oracle_pins.py pins to the reference's source text (quat2r, the Rodrigues matrix, S(theta), updateQuat as
+restated in oracle/okin.hpp from quaternion_algebra.cpp:302-318, B-splines by Cox - de Boor).  Oracle and product must
+give these numbers: this pins the LiDAR chain, the IMU chains and the time-offset node's Phi_dot c column.
+"""
+import numpy as np
+import pytest
+
+from multical_amd import spec as S
+from oracle_api import OracleApi
+from probe_api import ProbeApi
+
+mp = pytest.importorskip("mpmath")
+
+
+# ---------------------------------------------------------------------------------------------- primitives
+def _skew(v):
+    return mp.matrix([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def _C_of_theta(th):      # RotationVector::parametersToRotationMatrix (RotationVector.cpp:10-43): exp(-theta^)
+    phi = mp.norm(th)
+    K = _skew(th)
+    return mp.eye(3) - mp.sin(phi) / phi * K + (1 - mp.cos(phi)) / phi ** 2 * (K * K)
+
+
+def _S_of_theta(th):      # RotationVector::parametersToSMatrix (RotationVector.cpp:64-106)
+    phi = mp.norm(th)
+    K = _skew(th)
+    return mp.eye(3) - (1 - mp.cos(phi)) / phi ** 2 * K + (phi - mp.sin(phi)) / phi ** 3 * (K * K)
+
+
+def _quat2r(q):           # quaternion_algebra.cpp:77-101, q = [x y z w]
+    x, y, z, w = q
+    return mp.matrix([[x * x - y * y - z * z + w * w, 2 * (x * y + z * w), 2 * (x * z - y * w)],
+                      [2 * (x * y - z * w), -x * x + y * y - z * z + w * w, 2 * (x * w + y * z)],
+                      [2 * (x * z + y * w), 2 * (y * z - x * w), -x * x - y * y + z * z + w * w]])
+
+
+def _update_quat(q, dq):  # quaternion_algebra.cpp:302-318 (axisAngle2quat :200-221, qplus)
+    th = mp.sqrt(dq[0] ** 2 + dq[1] ** 2 + dq[2] ** 2)
+    na = mp.mpf(1) / 2 if th == 0 else mp.sin(th / 2) / th
+    d = [dq[0] * na, dq[1] * na, dq[2] * na, mp.cos(th / 2)]
+    return [q[0] * d[3] + d[0] * q[3] - d[1] * q[2] + d[2] * q[1],
+            q[1] * d[3] + d[0] * q[2] + d[1] * q[3] - d[2] * q[0],
+            q[2] * d[3] - d[0] * q[1] + d[1] * q[0] + d[2] * q[3],
+            q[3] * d[3] - d[0] * q[0] - d[1] * q[1] - d[2] * q[2]]
+
+
+def _ypr(yaw, pitch, roll):   # EulerAnglesYawPitchRoll.cpp:12-35
+    cx, sx, cy, sy, cz, sz = mp.cos(roll), mp.sin(roll), mp.cos(pitch), mp.sin(pitch), mp.cos(yaw), mp.sin(yaw)
+    return mp.matrix([[cz * cy, -sz * cx + cz * sy * sx, sz * sx + cz * sy * cx],
+                      [sz * cy, cz * cx + sz * sy * sx, -cz * sx + sz * sy * cx],
+                      [-sy, cy * sx, cy * cx]])
+
+
+def _direction(vec, dp):      # EuclideanDirection.cpp:5-52: magnitude * (C ypr(0, dp0, dp1)^T).col(2)
+    mag = mp.sqrt(vec[0] ** 2 + vec[1] ** 2 + vec[2] ** 2)
+    u = [v / mag for v in vec]
+    C = _ypr(0, mp.asin(-u[0]), mp.atan2(u[1], u[2])).T * _ypr(0, dp[0], dp[1]).T
+    return mp.matrix([mag * C[0, 2], mag * C[1, 2], mag * C[2, 2]])
+
+
+class _Spline(object):
+    def __init__(self, d):
+        self.order = d["order"]
+        self.knots = [mp.mpf(float(k)) for k in d["knots"]]
+        self.c = d["coeffs"]            # dim x n_coeff (float64)
+
+    def _basis(self, i, k, t, n):       # n-th derivative of the order-k basis function i (Cox - de Boor and its derivative form)
+        kn = self.knots
+        if n > 0:
+            a = mp.mpf(0)
+            d1, d2 = kn[i + k - 1] - kn[i], kn[i + k] - kn[i + 1]
+            if d1 > 0:
+                a += (k - 1) / d1 * self._basis(i, k - 1, t, n - 1)
+            if d2 > 0:
+                a -= (k - 1) / d2 * self._basis(i + 1, k - 1, t, n - 1)
+            return a
+        if k == 1:
+            return mp.mpf(1) if kn[i] <= t < kn[i + 1] else mp.mpf(0)
+        a = mp.mpf(0)
+        d1, d2 = kn[i + k - 1] - kn[i], kn[i + k] - kn[i + 1]
+        if d1 > 0:
+            a += (t - kn[i]) / d1 * self._basis(i, k - 1, t, 0)
+        if d2 > 0:
+            a += (kn[i + k] - t) / d2 * self._basis(i + 1, k - 1, t, 0)
+        return a
+
+    def live(self, t):
+        seg = max(j for j in range(len(self.knots) - 1) if self.knots[j] <= t)
+        return list(range(seg - self.order + 1, seg + 1))
+
+    def value(self, t, n, delta=None):
+        """n-th time derivative at t; delta = (coefficient index, component, amount) added to the coefficients"""
+        out = [mp.mpf(0)] * self.c.shape[0]
+        for i in self.live(t):
+            w = self._basis(i, self.order, t, n)
+            for dd in range(self.c.shape[0]):
+                cv = mp.mpf(float(self.c[dd, i]))
+                if delta is not None and delta[0] == i and delta[1] == dd:
+                    cv += delta[2]
+                out[dd] = out[dd] + w * cv
+        return out
+
+
+# ---------------------------------------------------------------------------------------------- the problem
+@pytest.fixture(scope="module")
+def tiny():
+    from multical_amd import synth
+    cfg = synth.SynthConfig(duration=1.0, n_cams=1, n_imus=1, n_lidars=1, lidar_points_per_frame=3, corner_stride=60)
+    spec, H, W, meas = synth.make_problem(cfg, OracleApi)
+    o, p = OracleApi(), ProbeApi()
+    ids = spec.emit(o)
+    spec.emit(p)
+    o.finalize()
+    p.finalize()
+    o.evaluate_error(False)
+    first = {}
+    base = 0
+    for i, k, d in spec.batch_ops():
+        first[i] = base
+        base += 1 if k == "motion" else len(d["sinv"])
+    return dict(spec=spec, o=o, p=p, ids=ids, first=first, bases=p.block_bases())
+
+
+class _State(object):
+    """design variables of the spec as mpmath values, with one perturbation: (handle, component, amount) in the design
+    variable's minimal coordinates, or ("coef", spline handle, coefficient, component, amount)"""
+
+    def __init__(self, spec, pert=None):
+        self.spec, self.pert = spec, pert
+
+    def _d(self, h, n):
+        out = [mp.mpf(0)] * n
+        if self.pert is not None and self.pert[0] == h:
+            out[self.pert[1]] = self.pert[2]
+        return out
+
+    def vec(self, h):
+        d = self.spec.ops[h][1]
+        v = [mp.mpf(float(x)) for x in d["params"]]
+        if d["kind"] == S.DV_EUCLIDEAN_DIRECTION:
+            return _direction(v, self._d(h, 2))
+        dv = self._d(h, len(v))
+        return mp.matrix([a + b for a, b in zip(v, dv)])
+
+    def mat(self, h):          # MatrixBasicDv (MatrixBasic.cpp:10-77): 3 x 3, additive on the flagged entries
+        d = self.spec.ops[h][1]
+        A = [mp.mpf(float(x)) for x in d["params"]]
+        flagged = [i for i in range(9) if d["pattern"][i]]
+        if self.pert is not None and self.pert[0] == h:
+            A[flagged[self.pert[1]]] += self.pert[2]
+        return mp.matrix([A[0:3], A[3:6], A[6:9]])
+
+    def rot(self, h):
+        d = self.spec.ops[h][1]
+        return _quat2r(_update_quat([mp.mpf(float(x)) for x in d["params"]], self._d(h, 3)))
+
+    def spline(self, h, t, n):
+        sp = _Spline(self.spec.ops[h][1])
+        delta = None
+        if self.pert is not None and self.pert[0] == "coef" and self.pert[1] == h:
+            delta = (self.pert[2], self.pert[3], self.pert[4])
+        return sp.value(t, n, delta)
+
+
+def _pose(st, hs, t):
+    """C_w_b, r_w, body rate, body 'angular acceleration', a_w at time t (BSplinePose.cpp:207-253, 288-331)"""
+    c0, c1, c2 = st.spline(hs, t, 0), st.spline(hs, t, 1), st.spline(hs, t, 2)
+    th = mp.matrix(c0[3:])
+    Cwb, Sm = _C_of_theta(th), _S_of_theta(th)
+    om = -(Cwb.T * (Sm * mp.matrix(c1[3:])))
+    al = -(Cwb.T * (Sm * mp.matrix(c2[3:])))
+    return Cwb, mp.matrix(c0[:3]), om, al, mp.matrix(c2[:3])
+
+
+def _lidar_residual(st, d, k):
+    t = mp.mpf(float(d["t"][k])) + (st.vec(d["dv_toff"])[0] if d["dv_toff"] is not None and d["dv_toff"] >= 0 else 0)
+    Cwb, rw, _, _, _ = _pose(st, d["spline"], t)
+    Clb, tlb = st.rot(d["dv_q_lb"]), st.vec(d["dv_t_lb"])
+    Cpw, tpw = st.rot(d["dv_q_pw"][k]), st.vec(d["dv_t_pw"][k])
+    # T_w_l = T_w_b inverse(T_l_b);  T_p_l = T_p_w T_w_l
+    Cwl = Cwb * Clb.T
+    twl = rw - Cwl * tlb
+    Cpl = Cpw * Cwl
+    tpl = Cpw * twl + tpw
+    dirv = mp.matrix([mp.mpf(float(x)) for x in d["dir"][k]])
+    pred = -tpl[2] / (Cpl * dirv)[2]
+    return [mp.mpf(float(d["sinv"][k])) * (pred - mp.mpf(float(d["range"][k])))]
+
+
+def _imu_residual(st, d, k, accel):
+    t = mp.mpf(float(d["t"][k]))
+    Cwb, rw, om, al, aw = _pose(st, d["pose_spline"], t)
+    Cib = st.rot(d["dv_q_ib"])
+    bias = mp.matrix(st.spline(d["bias_spline"], t, 0)) if d["bias_spline"] is not None and d["bias_spline"] >= 0 else st.vec(d["dv_bias"])
+    if accel:
+        g, rb = st.vec(d["dv_gravity"]), st.vec(d["dv_r_b"])
+        inner = Cwb.T * (aw - g) + _skew(al) * rb + _skew(om) * (_skew(om) * rb)
+    else:
+        inner = om
+    m = mp.matrix([mp.mpf(float(x)) for x in d["meas"][k]])
+    e = Cib * inner + bias - m
+    s = mp.mpf(float(d["sinv"][k]))
+    return [s * e[i] for i in range(3)]
+
+
+def _columns(tiny, handles, splines, t_eval):
+    """(perturbation, scalar column) for every active minimal coordinate of the given design-variable handles and of the
+    live coefficients of the given splines at their evaluation times"""
+    spec, o, ids, bases = tiny["spec"], tiny["o"], tiny["ids"], tiny["bases"]
+    out = []
+    for h in handles:
+        if h is None or h < 0:
+            continue
+        blk, col0 = o.dv_block(ids[h])
+        if blk < 0:
+            continue
+        for c in range(int(bases[blk + 1] - bases[blk])):
+            out.append(((h, c), col0 + c))
+    for hs, t in zip(splines, t_eval):
+        if hs is None or hs < 0:
+            continue
+        d = spec.ops[hs][1]
+        sid = ids[hs][1]
+        for i in _Spline(d).live(t):
+            blk, col0 = o.dv_block(o.spline_first_dv(sid) + i)
+            if blk < 0:
+                continue
+            for c in range(d["coeffs"].shape[0]):
+                out.append((("coef", hs, i, c), col0 + c))
+    return out
+
+
+def _check(tiny, term, residual, columns, tol_e=1e-12, tol_j=1e-10):
+    o, p, spec = tiny["o"], tiny["p"], tiny["spec"]
+    Jo, eo = o.term_weighted_jacobian(term, False)
+    Jp, ep, _ = p.term(term, False)
+    e0 = np.array([float(v) for v in residual(_State(spec))])
+    scale_e = max(1.0, np.abs(e0).max())
+    assert np.abs(eo - e0).max() <= tol_e * scale_e, (eo, e0)
+    assert np.abs(ep - e0).max() <= tol_e * scale_e, (ep, e0)
+    want = np.zeros_like(Jo)
+    for pert, col in columns:
+        def f(x, pert=pert):
+            return residual(_State(spec, pert + (x,)))
+        for r in range(len(e0)):
+            want[r, col] = float(mp.diff(lambda x, r=r: f(x)[r], mp.mpf(0)))
+    scale = np.abs(want).max()
+    assert scale > 0
+    assert np.abs(Jo - want).max() <= tol_j * scale, np.abs(Jo - want).max() / scale
+    assert np.abs(Jp - want).max() <= tol_j * scale, np.abs(Jp - want).max() / scale
+    touched = sorted(set(c for _, c in columns))
+    assert np.count_nonzero(np.abs(Jo).max(0)) <= len(touched)       # nothing outside the columns differentiated
+
+
+def _batches(tiny, kind):
+    return [(i, d) for i, k, d in tiny["spec"].batch_ops() if k == kind]
+
+
+def test_lidar_point_to_plane_term(tiny):
+    mp.mp.dps = 40
+    i, d = _batches(tiny, "lidar")[0]
+    for k in (0, len(d["sinv"]) // 2):
+        t = mp.mpf(float(d["t"][k])) + mp.mpf(float(tiny["spec"].ops[d["dv_toff"]][1]["params"][0]))
+        cols = _columns(tiny, [d["dv_toff"], d["dv_q_lb"], d["dv_t_lb"], d["dv_q_pw"][k], d["dv_t_pw"][k]], [d["spline"]], [t])
+        assert len(cols) >= 36 + 6
+        _check(tiny, tiny["first"][i] + k, lambda st: _lidar_residual(st, d, k), cols)
+
+
+def test_gyroscope_term(tiny):
+    mp.mp.dps = 40
+    i, d = _batches(tiny, "gyro")[0]
+    k = len(d["sinv"]) // 3
+    t = mp.mpf(float(d["t"][k]))
+    cols = _columns(tiny, [d["dv_q_ib"], d["dv_bias"]], [d["pose_spline"], d["bias_spline"]], [t, t])
+    _check(tiny, tiny["first"][i] + k, lambda st: _imu_residual(st, d, k, False), cols)
+
+
+def test_accelerometer_term(tiny):
+    mp.mp.dps = 40
+    i, d = _batches(tiny, "accel")[0]
+    k = len(d["sinv"]) // 2
+    t = mp.mpf(float(d["t"][k]))
+    cols = _columns(tiny, [d["dv_q_ib"], d["dv_bias"], d["dv_gravity"], d["dv_r_b"]], [d["pose_spline"], d["bias_spline"]], [t, t])
+    _check(tiny, tiny["first"][i] + k, lambda st: _imu_residual(st, d, k, True), cols)
+
+
+# ---------------------------------------------------------------------------------------------- the other IMU models
+def _body(st, d, t):
+    Cwb, rw, om, al, aw = _pose(st, d["pose_spline"], t)
+    return Cwb, om, al, aw, st.vec(d["dv_gravity"]), st.vec(d["dv_r_b"])
+
+
+def _lever(om, al, r):
+    return _skew(al) * r + _skew(om) * (_skew(om) * r)
+
+
+def _accel_sm_residual(st, d, k):
+    t = mp.mpf(float(d["t"][k]))
+    Cwb, om, al, aw, g, rb = _body(st, d, t)
+    Cib, M = st.rot(d["dv_q_ib"]), st.mat(d["dv_M"])
+    if d["size_effect"] is None:
+        a = M * (Cib * (Cwb.T * (aw - g) + _lever(om, al, rb)))
+    else:
+        arms, sel = d["size_effect"][:3], d["size_effect"][3:]
+        inner = Cib * (Cwb.T * (aw - g))
+        for ha, hs in zip(arms, sel):
+            inner = inner + st.mat(hs) * (Cib * _lever(om, al, rb + Cib.T * st.vec(ha)))
+        a = M * inner
+    bias = mp.matrix(st.spline(d["bias_spline"], t, 0))
+    m = mp.matrix([mp.mpf(float(x)) for x in d["meas"][k]])
+    e = a + bias - m
+    return [mp.mpf(float(d["sinv"][k])) * e[i] for i in range(3)]
+
+
+def _gyro_sm_residual(st, d, k):
+    t = mp.mpf(float(d["t"][k]))
+    Cwb, om, al, aw, g, rb = _body(st, d, t)
+    a_b = Cwb.T * (aw - g) + _lever(om, al, rb)
+    Cgb = st.rot(d["dv_q_gi"]) * st.rot(d["dv_q_ib"])
+    w = st.mat(d["dv_M"]) * (Cgb * om) + st.mat(d["dv_Ma"]) * (Cgb * a_b)
+    bias = mp.matrix(st.spline(d["bias_spline"], t, 0))
+    m = mp.matrix([mp.mpf(float(x)) for x in d["meas"][k]])
+    e = w + bias - m
+    return [mp.mpf(float(d["sinv"][k])) * e[i] for i in range(3)]
+
+
+@pytest.fixture(scope="module", params=["scale_misalignment", "size_effect"])
+def tiny_sm(request, tiny):
+    from test_variants import make_variant
+    spec = make_variant(tiny["spec"], request.param)
+    o, p = OracleApi(), ProbeApi()
+    ids = spec.emit(o)
+    spec.emit(p)
+    o.finalize()
+    p.finalize()
+    o.evaluate_error(False)
+    first, base = {}, 0
+    for i, k, d in spec.batch_ops():
+        first[i] = base
+        base += 1 if k == "motion" else len(d["sinv"])
+    return dict(spec=spec, o=o, p=p, ids=ids, first=first, bases=p.block_bases(), model=request.param)
+
+
+def test_accelerometer_term_of_the_other_imu_models(tiny_sm):
+    mp.mp.dps = 40
+    i, d = _batches(tiny_sm, "accel_sm")[0]
+    k = len(d["sinv"]) // 2
+    t = mp.mpf(float(d["t"][k]))
+    handles = [d["dv_q_ib"], d["dv_gravity"], d["dv_r_b"], d["dv_M"]] + (list(d["size_effect"]) if d["size_effect"] is not None else [])
+    cols = _columns(tiny_sm, handles, [d["pose_spline"], d["bias_spline"]], [t, t])
+    _check(tiny_sm, tiny_sm["first"][i] + k, lambda st: _accel_sm_residual(st, d, k), cols)
+
+
+def test_gyroscope_term_of_the_other_imu_models(tiny_sm):
+    mp.mp.dps = 40
+    i, d = _batches(tiny_sm, "gyro_sm")[0]
+    k = len(d["sinv"]) // 3
+    t = mp.mpf(float(d["t"][k]))
+    handles = [d["dv_q_ib"], d["dv_q_gi"], d["dv_M"], d["dv_Ma"], d["dv_gravity"], d["dv_r_b"]]
+    cols = _columns(tiny_sm, handles, [d["pose_spline"], d["bias_spline"]], [t, t])
+    _check(tiny_sm, tiny_sm["first"][i] + k, lambda st: _gyro_sm_residual(st, d, k), cols)
