@@ -1,5 +1,5 @@
-"""Whole error terms from first principles at 40 digits (mpmath): the LiDAR point-to-plane term, the gyroscope and the
-accelerometer term of the calibrated IMU model and of the scale-misalignment / size-effect models -- residual AND every
+"""Whole error terms from first principles at 40 digits (mpmath): the reprojection terms (through the pose spline, all camera
+models; static with camera design variables), the LiDAR point-to-plane term, the gyroscope and the accelerometer term of the calibrated IMU model and of the scale-misalignment / size-effect models -- residual AND every
 Jacobian column, the latter by 40-digit differentiation
 of the residual along each design variable's own update rule (additive; RotationQuaternion: updateQuat; EuclideanDirection:
 C <- C * ypr(0, dp0, dp1)^T; the time offset moves the spline's evaluation time).  Nothing of the oracle's or the product's
@@ -370,3 +370,125 @@ def test_gyroscope_term_of_the_other_imu_models(tiny_sm):
     handles = [d["dv_q_ib"], d["dv_q_gi"], d["dv_M"], d["dv_Ma"], d["dv_gravity"], d["dv_r_b"]]
     cols = _columns(tiny_sm, handles, [d["pose_spline"], d["bias_spline"]], [t, t])
     _check(tiny_sm, tiny_sm["first"][i] + k, lambda st: _gyro_sm_residual(st, d, k), cols)
+
+
+# ---------------------------------------------------------------------------------------------- reprojection terms (F1, F2)
+def _distort(kind, k, y):
+    if kind == S.DIST_NONE:
+        return y
+    if kind == S.DIST_RADTAN:      # RadialTangentialDistortion.hpp:4-26
+        k1, k2, p1, p2 = k
+        mx2, my2, mxy = y[0] * y[0], y[1] * y[1], y[0] * y[1]
+        rho2 = mx2 + my2
+        rad = k1 * rho2 + k2 * rho2 * rho2
+        return [y[0] + y[0] * rad + 2 * p1 * mxy + p2 * (rho2 + 2 * mx2), y[1] + y[1] * rad + 2 * p2 * mxy + p1 * (rho2 + 2 * my2)]
+    r = mp.sqrt(y[0] * y[0] + y[1] * y[1])      # EquidistantDistortion.hpp:4-30
+    th = mp.atan(r)
+    thd = th * (1 + k[0] * th ** 2 + k[1] * th ** 4 + k[2] * th ** 6 + k[3] * th ** 8)
+    return [y[0] * thd / r, y[1] * thd / r]
+
+
+def _project(model, dist, proj, dk, p):
+    if model == S.PROJ_PINHOLE:     # PinholeProjection.hpp:73-97
+        fu, fv, cu, cv = proj
+        y = _distort(dist, dk, [p[0] / p[2], p[1] / p[2]])
+    elif model == S.PROJ_OMNI:      # OmniProjection.hpp:72-107
+        xi, fu, fv, cu, cv = proj
+        d = mp.sqrt(p[0] ** 2 + p[1] ** 2 + p[2] ** 2)
+        y = _distort(dist, dk, [p[0] / (p[2] + xi * d), p[1] / (p[2] + xi * d)])
+    else:                           # DoubleSphereProjection.hpp:90-140
+        xi, alpha, fu, fv, cu, cv = proj
+        d1 = mp.sqrt(p[0] ** 2 + p[1] ** 2 + p[2] ** 2)
+        k = xi * d1 + p[2]
+        d2 = mp.sqrt(p[0] ** 2 + p[1] ** 2 + k * k)
+        norm = alpha * d2 + (1 - alpha) * k
+        y = [p[0] / norm, p[1] / norm]
+    return [fu * y[0] + cu, fv * y[1] + cv]
+
+
+def _camera(st, hc):
+    c = st.spec.ops[hc][1]
+    proj = list(st.vec(c["dv_proj"]))
+    dk = list(st.vec(c["dv_dist"])) if c["dv_dist"] is not None and c["dv_dist"] >= 0 else []
+    return c["model"], c["dist"], proj, dk
+
+
+def _reproj_residual(st, d, k):
+    u = int(np.searchsorted(d["obs_first"], k, side="right") - 1)
+    t = mp.mpf(float(d["obs_time"][u])) + (st.vec(d["dv_toff"])[0] if d["dv_toff"] is not None and d["dv_toff"] >= 0 else 0)
+    Cwb, rw, _, _, _ = _pose(st, d["spline"], t)
+    Ccb, tcb = st.rot(d["dv_q_cb"]), st.vec(d["dv_t_cb"])
+    Cpw, tpw = st.rot(d["obs_dv_q_pw"][u]), st.vec(d["obs_dv_t_pw"][u])
+    # p_c = T_c_b inverse(T_w_b) inverse(T_p_w) p      (sensors_and_targets.py:571-611)
+    pt = mp.matrix([mp.mpf(float(x)) for x in d["p"][k]])
+    pw = Cpw.T * (pt - tpw)
+    pb = Cwb.T * (pw - rw)
+    pc = Ccb * pb + tcb
+    kp = _project(*_camera(st, d["camera"]), pc)
+    s = mp.mpf(float(d["sinv"][k]))
+    return [s * (mp.mpf(float(d["y"][k, 0])) - kp[0]), s * (mp.mpf(float(d["y"][k, 1])) - kp[1])]
+
+
+def _static_residual(st, d, k):
+    u = int(np.searchsorted(d["obs_first"], k, side="right") - 1)
+    Ctc, ttc = st.rot(d["obs_dv_q_tc"][u]), st.vec(d["obs_dv_t_tc"][u])
+    # p_c = B_{n-1} ... B_0 inverse(T_t_c) p      (CameraCalibrator.py:195-212)
+    pt = mp.matrix([mp.mpf(float(x)) for x in d["p"][k]])
+    pc = Ctc.T * (pt - ttc)
+    for hq, ht in zip(d["chain_dv_q"], d["chain_dv_t"]):
+        pc = st.rot(hq) * pc + st.vec(ht)
+    kp = _project(*_camera(st, d["camera"]), pc)
+    s = mp.mpf(float(d["sinv"][k]))
+    return [s * (mp.mpf(float(d["y"][k, 0])) - kp[0]), s * (mp.mpf(float(d["y"][k, 1])) - kp[1])]
+
+
+def _problem(spec):
+    o, p = OracleApi(), ProbeApi()
+    ids = spec.emit(o)
+    spec.emit(p)
+    o.finalize()
+    p.finalize()
+    o.evaluate_error(False)
+    first, base = {}, 0
+    for i, k, d in spec.batch_ops():
+        first[i] = base
+        base += 1 if k == "motion" else len(d["sinv"])
+    return dict(spec=spec, o=o, p=p, ids=ids, first=first, bases=p.block_bases())
+
+
+def test_reprojection_term_through_the_pose_spline():
+    """F1, one corner per camera model: pinhole + radial-tangential, omni + radial-tangential, double sphere, pinhole + equidistant"""
+    mp.mp.dps = 40
+    from multical_amd import synth
+    cfg = synth.SynthConfig(duration=1.0, n_cams=4, n_imus=1, n_lidars=0, corner_stride=20,
+                            cam_models=[(S.PROJ_PINHOLE, S.DIST_RADTAN), (S.PROJ_OMNI, S.DIST_RADTAN), (S.PROJ_DS, S.DIST_NONE), (S.PROJ_PINHOLE, S.DIST_EQUI)])
+    pr = _problem(synth.make_problem(cfg, OracleApi)[0])
+    seen = set()
+    for i, d in _batches(pr, "reproj"):
+        if len(d["sinv"]) == 0 or d["camera"] in seen:
+            continue
+        seen.add(d["camera"])
+        k = len(d["sinv"]) // 2
+        u = int(np.searchsorted(d["obs_first"], k, side="right") - 1)
+        t = mp.mpf(float(d["obs_time"][u])) + mp.mpf(float(pr["spec"].ops[d["dv_toff"]][1]["params"][0]))
+        cols = _columns(pr, [d["dv_toff"], d["dv_q_cb"], d["dv_t_cb"], d["obs_dv_q_pw"][u], d["obs_dv_t_pw"][u]], [d["spline"]], [t])
+        assert len(cols) >= 36
+        _check(pr, pr["first"][i] + k, lambda st: _reproj_residual(st, d, k), cols)
+    assert len(seen) == 4
+
+
+def test_static_reprojection_term_with_camera_design_variables():
+    """F2 (camera calibration): target pose, baseline chain, projection and distortion parameters all design variables"""
+    mp.mp.dps = 40
+    from multical_amd import synth_static as SS
+    cfg = SS.StaticConfig(n_cams=3, n_boards=1, n_views=3, corner_stride=30,
+                          cam_models=[(S.PROJ_PINHOLE, S.DIST_RADTAN), (S.PROJ_OMNI, S.DIST_RADTAN), (S.PROJ_DS, S.DIST_NONE)])
+    pr = _problem(SS.make_static_problem(cfg, OracleApi)[0])
+    for i, d in _batches(pr, "static_reproj"):
+        k = len(d["sinv"]) // 2
+        u = int(np.searchsorted(d["obs_first"], k, side="right") - 1)
+        cam = pr["spec"].ops[d["camera"]][1]
+        handles = [d["obs_dv_q_tc"][u], d["obs_dv_t_tc"][u], cam["dv_proj"], cam["dv_dist"]] + list(d["chain_dv_q"]) + list(d["chain_dv_t"])
+        cols = _columns(pr, handles, [], [])
+        assert len(cols) >= 6 + 4
+        _check(pr, pr["first"][i] + k, lambda st: _static_residual(st, d, k), cols)
