@@ -492,3 +492,78 @@ def test_static_reprojection_term_with_camera_design_variables():
         cols = _columns(pr, handles, [], [])
         assert len(cols) >= 6 + 4
         _check(pr, pr["first"][i] + k, lambda st: _static_residual(st, d, k), cols)
+
+
+# ---------------------------------------------------------------------------------------------- initialisation terms (F6), landmarks (C8)
+def _r2_axis_angle(C):       # sm_kinematics rotations.cpp:133-157
+    a = mp.acos((C[0, 0] + C[1, 1] + C[2, 2] - 1) / 2)
+    ax = mp.matrix([C[2, 1] - C[1, 2], C[0, 2] - C[2, 0], C[1, 0] - C[0, 1]])
+    return ax * (-a / mp.norm(ax))
+
+
+def _transformation_residual(st, d, k):
+    # ErrorTermTransformation.cpp:19-81: [t; R2AxisAngle(C)] of T * inverse(prior), T = T_a or T_a * inverse(T_b)
+    Ca, ta = st.rot(d["dv_q_a"]), st.vec(d["dv_t_a"])
+    if d["dv_q_b"] is not None and d["dv_q_b"] >= 0:
+        Cb, tb = st.rot(d["dv_q_b"]), st.vec(d["dv_t_b"])
+        Ca, ta = Ca * Cb.T, ta - Ca * Cb.T * tb
+    Cp = _quat2r([mp.mpf(float(x)) for x in d["prior_q"][k]])
+    tp = mp.matrix([mp.mpf(float(x)) for x in d["prior_t"][k]])
+    Ce, te = Ca * Cp.T, ta - Ca * Cp.T * tp
+    aa = _r2_axis_angle(Ce)
+    wt, wr = mp.sqrt(mp.mpf(d["weight_translation"])), mp.sqrt(mp.mpf(d["weight_rotation"]))
+    return [wt * te[0], wt * te[1], wt * te[2], wr * aa[0], wr * aa[1], wr * aa[2]]
+
+
+def _gyro_prior_residual(st, d, k):
+    # kalibr GyroscopeError over a constant rate (GyroscopeError.cpp:5-17): C(q_i_c) w_c + b_g - w_meas
+    e = st.rot(d["dv_q"]) * mp.matrix([mp.mpf(float(x)) for x in d["w_pred"][k]]) + st.vec(d["dv_bias"]) - \
+        mp.matrix([mp.mpf(float(x)) for x in d["meas"][k]])
+    s = mp.mpf(float(d["sinv"][k]))
+    return [s * e[i] for i in range(3)]
+
+
+def test_initialisation_problem_terms():
+    mp.mp.dps = 40
+    from multical_amd import synth_init as SI
+    for spec in (SI.make_target_pose_prior()[0], SI.make_extrinsic_prior(n_gyro=20)[0]):
+        pr = _problem(spec)
+        for i, d in _batches(pr, "transformation"):
+            k = len(d["sinv"]) // 2
+            cols = _columns(pr, [d["dv_q_a"], d["dv_t_a"], d["dv_q_b"], d["dv_t_b"]], [], [])
+            _check(pr, pr["first"][i] + k, lambda st: _transformation_residual(st, d, k), cols)
+        for i, d in _batches(pr, "gyro_prior"):
+            k = len(d["sinv"]) // 2
+            cols = _columns(pr, [d["dv_q"], d["dv_bias"]], [], [])
+            _check(pr, pr["first"][i] + k, lambda st: _gyro_prior_residual(st, d, k), cols)
+
+
+def _landmark_residual(st, d, k):
+    # the target point is a HomogeneousPoint design variable (HomogeneousPoint.cpp: unit 4-vector, update by updateQuat)
+    u = int(np.searchsorted(d["obs_first"], k, side="right") - 1)
+    h = d["landmarks"][k]
+    ph = _update_quat([mp.mpf(float(x)) / mp.sqrt(sum(mp.mpf(float(y)) ** 2 for y in st.spec.ops[h][1]["params"])) for x in st.spec.ops[h][1]["params"]],
+                      st._d(h, 3))
+    Ctc, ttc = st.rot(d["obs_dv_q_tc"][u]), st.vec(d["obs_dv_t_tc"][u])
+    pc = Ctc.T * (mp.matrix(ph[:3]) - ph[3] * ttc)             # inverse(T_t_c) * p_h, kept homogeneous (w = ph[3])
+    w = ph[3]
+    for hq, ht in zip(d["chain_dv_q"], d["chain_dv_t"]):
+        pc = st.rot(hq) * pc + w * st.vec(ht)
+    kp = _project(*_camera(st, d["camera"]), pc)
+    s = mp.mpf(float(d["sinv"][k]))
+    return [s * (mp.mpf(float(d["y"][k, 0])) - kp[0]), s * (mp.mpf(float(d["y"][k, 1])) - kp[1])]
+
+
+def test_static_reprojection_term_over_a_landmark():
+    mp.mp.dps = 40
+    from multical_amd import synth_static as SS
+    cfg = SS.StaticConfig(n_cams=2, n_boards=1, n_views=3, corner_stride=30, cam_models=[(S.PROJ_PINHOLE, S.DIST_RADTAN), (S.PROJ_OMNI, S.DIST_RADTAN)])
+    spec = SS.with_landmarks(SS.make_static_problem(cfg, OracleApi)[0], inactive_every=0, constant_every=0)
+    pr = _problem(spec)
+    for i, d in _batches(pr, "static_reproj"):
+        k = len(d["sinv"]) // 2
+        u = int(np.searchsorted(d["obs_first"], k, side="right") - 1)
+        cam = pr["spec"].ops[d["camera"]][1]
+        handles = [d["landmarks"][k], d["obs_dv_q_tc"][u], d["obs_dv_t_tc"][u], cam["dv_proj"], cam["dv_dist"]] + list(d["chain_dv_q"]) + list(d["chain_dv_t"])
+        cols = _columns(pr, handles, [], [])
+        _check(pr, pr["first"][i] + k, lambda st: _landmark_residual(st, d, k), cols)
