@@ -165,6 +165,13 @@ int orc_u_quat2r(const double* q, double* R) {
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = M(i, j);
   return 0;
 }
+// MEstimator::getWeight (MEstimatorPolicies.cpp:17-129): n weights for squared errors e2[i], kind / parameter as in oterms.hpp
+int orc_u_mest_weights(int kind, double a, int n, const double* e2, double* w) {
+  MEstimator m;
+  m.kind = kind; m.a = a;
+  for (int i = 0; i < n; ++i) w[i] = m.getWeight(e2[i]);
+  return 0;
+}
 int orc_u_rv_rotation_matrix(const double* p, double* Cm) {
   Mat M = rvRotationMatrix(Mat::Vec({p[0], p[1], p[2]}));
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Cm[3 * i + j] = M(i, j);

@@ -38,7 +38,7 @@ REF = os.environ.get("MULTICAL_REFERENCE", "/root/reference")
 RV_FILE = "Schweizer-Messer/sm_kinematics/src/RotationVector.cpp"
 EQ_FILE = "aslam_cv/aslam_cameras/include/aslam/cameras/implementation/EquidistantDistortion.hpp"
 
-_FUNCS = {"pow": math.pow, "sqrt": math.sqrt, "sin": math.sin, "cos": math.cos, "atan": math.atan}
+_FUNCS = {"pow": math.pow, "sqrt": math.sqrt, "sin": math.sin, "cos": math.cos, "atan": math.atan, "exp": math.exp}
 _TOKEN = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][-+]?\d+)?|\d+)|([A-Za-z_]\w*)|([-+*/(),]))")
 
 
@@ -90,7 +90,7 @@ def _run(stmts, env):
 # `p[0]` -> `p0`, `J(i, j)` -> `J_i_j`, `std::sqrt` -> `sqrt`, `double(1.0)` -> `1.0`, `(c) ? a : b` -> Python's
 # conditional.  Every expression is token-checked (numbers, known names, + - * / ( ) , > and sqrt / atan / pow); a line
 # of the block that is not such a statement must be named in `skip` (a regular expression) or the script stops.
-_TOKEN2 = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][-+]?\d+)?)|([A-Za-z_]\w*)|([-+*/(),>]))")
+_TOKEN2 = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][-+]?\d+)?)|([A-Za-z_]\w*)|([-+*/(),><]))")
 _KEYWORDS = {"if", "else"}
 
 
@@ -354,6 +354,31 @@ def kinematics_vectors(rng, n=32):
     return dict(kin_q=Q, kin_quat2r=R, kin_rv=Pm, kin_rv_C=Cm)
 
 
+ME_FILE = "aslam_optimizer/aslam_backend/src/MEstimatorPolicies.cpp"
+
+
+def mestimator_vectors(rng, n=40):
+    """MEstimator::getWeight of the five robust kernels (MEstimatorPolicies.cpp:30-33, 46-49, 62-64, 77-79, 114-116): the
+    bodies read as `w = expr` (`return` renamed), members `_sigma2`, `_k`, `_k2`, `_epsilon` as inputs"""
+    bodies = dict(geman_mcclure=(31, 32), cauchy=(47, 48), huber=(63, 63), bz=(78, 78), blake_zisserman=(115, 115))
+    out = {}
+    e2 = np.concatenate([[0.0, 1e-12], np.exp(rng.uniform(-6, 6, n - 2))])
+    a = np.exp(rng.uniform(-2, 2, n))
+    out["mest_e2"], out["mest_a"] = e2, a
+    for name, (lo, hi) in bodies.items():
+        text = _lines(ME_FILE, lo, hi).replace("return ", "w = ")
+        text = re.sub(r"w = ([^?;()]+?)\s*\?", r"w = (\1) ?", text)          # Huber's condition carries no parentheses
+        prog = _program_from_text(text, [], None, "%s:%d-%d" % (ME_FILE, lo, hi))
+        W = np.zeros((n, n))
+        for i in range(n):
+            for j in range(n):
+                env = dict(error=float(e2[i]), mahalanobis2=float(e2[i]), sigma2=float(a[j]), k=float(a[j]), k2=float(a[j]) * float(a[j]),
+                           epsilon=float(a[j]))
+                W[i, j] = _exec(prog, env)["w"]
+        out["mest_w_" + name] = W
+    return out
+
+
 def generate():
     rng = np.random.Generator(np.random.PCG64(20221023))
     out = {}
@@ -361,6 +386,7 @@ def generate():
     out.update(equidistant_vectors(rng))
     out.update(camera_vectors(rng))
     out.update(kinematics_vectors(rng))
+    out.update(mestimator_vectors(rng))      # last: the vectors above keep their random stream
     return out
 
 

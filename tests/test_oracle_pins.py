@@ -146,6 +146,23 @@ def test_quat2r_and_rodrigues_against_the_reference_source():
 
 
 # ------------------------------------------------------------------------------------------ 2a. evalD == spalde
+def test_mestimator_weights_against_the_reference_source():
+    """MEstimator::getWeight of the five robust kernels as MEstimatorPolicies.cpp:30-33, 46-49, 62-64, 77-79, 114-116 state
+    them (golden vectors from the source text), oracle and product, on a 40 x 40 grid of squared errors and parameters."""
+    g = np.load(GOLD)
+    o, p = _olib(), _plib()
+    kinds = dict(huber=1, cauchy=2, geman_mcclure=3, bz=4, blake_zisserman=5)
+    e2 = np.ascontiguousarray(g["mest_e2"])
+    for name, kind in kinds.items():
+        want = g["mest_w_" + name]
+        for j, a in enumerate(g["mest_a"]):
+            wo, wp = np.zeros(e2.size), np.zeros(e2.size)
+            o.orc_u_mest_weights(kind, C.c_double(float(a)), e2.size, _d(e2), _d(wo))
+            p.probe_u_mest_weights(kind, C.c_double(float(a)), e2.size, _d(e2), _d(wp))
+            assert np.abs(wo - want[:, j]).max() <= 1e-15 * max(1.0, np.abs(want[:, j]).max()), (name, j)
+            assert np.abs(wp - want[:, j]).max() <= 1e-15 * max(1.0, np.abs(want[:, j]).max()), (name, j)
+
+
 def _spline_case(order, knots, rng):
     kr = knots.size
     kc = kr - order                       # numCoefficientsRequired: knots - order
