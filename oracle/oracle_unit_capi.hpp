@@ -172,6 +172,12 @@ int orc_u_mest_weights(int kind, double a, int n, const double* e2, double* w) {
   for (int i = 0; i < n; ++i) w[i] = m.getWeight(e2[i]);
   return 0;
 }
+// sm::kinematics::updateQuat (quaternion_algebra.cpp:302-318): what RotationQuaternion / HomogeneousPoint::update apply
+int orc_u_update_quat(const double* q, const double* dq, double* out) {
+  Mat r = updateQuat(Mat::Vec({q[0], q[1], q[2], q[3]}), Mat::Vec({dq[0], dq[1], dq[2]}));
+  for (int i = 0; i < 4; ++i) out[i] = r[i];
+  return 0;
+}
 int orc_u_rv_rotation_matrix(const double* p, double* Cm) {
   Mat M = rvRotationMatrix(Mat::Vec({p[0], p[1], p[2]}));
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Cm[3 * i + j] = M(i, j);

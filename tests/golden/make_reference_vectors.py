@@ -379,6 +379,26 @@ def mestimator_vectors(rng, n=40):
     return out
 
 
+def update_quat_vectors(rng, n=32):
+    """sm::kinematics::updateQuat (quaternion_algebra.cpp:302-318) through axisAngle2quat's regular branch (:216, :219):
+    na and ct as the source states them, the axis product `a * na` component-wise, then the four retq statements"""
+    aa = _program_from_text(_lines(QA_FILE, 216, 216) + _lines(QA_FILE, 219, 219), [], None, QA_FILE + ":216,219")
+    uq = _program_from_text(_lines(QA_FILE, 310, 310) + _lines(QA_FILE, 312, 315), ["q", "dq3", "retq"], None, QA_FILE + ":310-315")
+    Q, D, R = np.zeros((n, 4)), np.zeros((n, 3)), np.zeros((n, 4))
+    for k in range(n):
+        q = rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        dq = rng.standard_normal(3) * (10.0 ** rng.uniform(-3, 0.3))     # above the small-angle branch (theta > eps^(1/4) = 1.2e-4)
+        theta = float(np.linalg.norm(dq))
+        e = _exec(aa, dict(theta=theta))
+        env = {"q%d" % i: float(q[i]) for i in range(4)}
+        env.update({"dq3%d" % i: float(dq[i]) * e["na"] for i in range(3)})
+        env["dq33"] = e["ct"]
+        r = _exec(uq, env)
+        Q[k], D[k], R[k] = q, dq, [r["retq%d" % i] for i in range(4)]
+    return dict(uq_q=Q, uq_dq=D, uq_out=R)
+
+
 def generate():
     rng = np.random.Generator(np.random.PCG64(20221023))
     out = {}
@@ -386,7 +406,8 @@ def generate():
     out.update(equidistant_vectors(rng))
     out.update(camera_vectors(rng))
     out.update(kinematics_vectors(rng))
-    out.update(mestimator_vectors(rng))      # last: the vectors above keep their random stream
+    out.update(mestimator_vectors(rng))      # appended in this order: the vectors above keep their random stream
+    out.update(update_quat_vectors(rng))
     return out
 
 

@@ -374,6 +374,7 @@ int probe_u_mest_weights(int kind, double a, int n, const double* e2, double* w)
   for (int i = 0; i < n; ++i) w[i] = mest_weight<true>(kind, a, e2[i]);
   return 0;
 }
+int probe_u_update_quat(const double* q, const double* dq, double* out) { update_quat(q, dq, out); return 0; }
 int probe_u_quat2r(const double* q, double* R) { quat2r(q, R); return 0; }
 int probe_u_rotvec_C(const double* th, double* Cm) { double S[9]; rotvec_C_S(th, Cm, S); return 0; }
 // project / intrinsics_jacobian / distortion_jacobian of mc_math.h for one point: kp[2], Jp 2 x 3, Ji 2 x projDims,

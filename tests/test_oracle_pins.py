@@ -146,6 +146,19 @@ def test_quat2r_and_rodrigues_against_the_reference_source():
 
 
 # ------------------------------------------------------------------------------------------ 2a. evalD == spalde
+def test_update_quat_against_the_reference_source():
+    """sm::kinematics::updateQuat (quaternion_algebra.cpp:302-318, with axisAngle2quat's regular branch :216-219): the state
+    update of every RotationQuaternion and HomogeneousPoint design variable (row A4), oracle and product (the product's
+    device kernel k_update calls the same update_quat)."""
+    g = np.load(GOLD)
+    o, p = _olib(), _plib()
+    for q, dq, want in zip(g["uq_q"], g["uq_dq"], g["uq_out"]):
+        a, b = np.zeros(4), np.zeros(4)
+        o.orc_u_update_quat(_d(q.copy()), _d(dq.copy()), _d(a))
+        p.probe_u_update_quat(_d(q.copy()), _d(dq.copy()), _d(b))
+        assert np.abs(a - want).max() <= 1e-15 and np.abs(b - want).max() <= 1e-15
+
+
 def test_mestimator_weights_against_the_reference_source():
     """MEstimator::getWeight of the five robust kernels as MEstimatorPolicies.cpp:30-33, 46-49, 62-64, 77-79, 114-116 state
     them (golden vectors from the source text), oracle and product, on a 40 x 40 grid of squared errors and parameters."""
