@@ -115,16 +115,20 @@ def main():
     dCx = torch.zeros(api.nnz, dtype=torch.float64, device=dev)
     dE = torch.zeros(api.j_rows, dtype=torch.float64, device=dev)     # the stacked weighted residual evaluateError returns
     stream = torch.cuda.current_stream().cuda_stream
-    # One exchange buffer per step: [ Cx entries shared between ranks | rhs | J ].  rhs and J are written straight into it
-    # by the entry points, the shared entries are gathered by mc_pack_shared: ONE all-reduce per Gauss-Newton iteration.
+    # One exchange buffer per step: [ Cx entries shared between ranks | rhs entries shared between ranks | J ].  J is written
+    # straight into it by the entry points, the shared entries are gathered by mc_pack_shared / mc_pack_shared_rhs: ONE
+    # all-reduce per Gauss-Newton iteration, of the entries more than one rank writes and nothing else.
     n_shared = len(api.shared_indices()) if world > 1 else 0
-    xbuf = torch.zeros(n_shared + api.j_cols + 1, dtype=torch.float64, device=dev)
-    dshared, drhs, dJ = xbuf[:n_shared], xbuf[n_shared:n_shared + api.j_cols], xbuf[n_shared + api.j_cols:]
+    n_shared_rhs = len(api.shared_rhs_indices()) if world > 1 else 0
+    xbuf = torch.zeros(n_shared + n_shared_rhs + 1, dtype=torch.float64, device=dev)
+    dshared, dshared_rhs, dJ = xbuf[:n_shared], xbuf[n_shared:n_shared + n_shared_rhs], xbuf[n_shared + n_shared_rhs:]
+    drhs = torch.zeros(api.j_cols, dtype=torch.float64, device=dev)
 
     def exchange():
         # partial Hessians: only the entries two ranks can write (window halos, global x global blocks) are summed;
         # every other entry already sits complete on the rank that owns its time window
         api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
+        api.pack_shared_rhs(drhs.data_ptr(), dshared_rhs.data_ptr(), stream)
         tr("packed")
         if rehearse and os.environ.get("MC_BENCH_GLOO_DEVICE") != "1":
             h = xbuf.cpu()            # gloo on host memory (DESIGN.md section 6 has what its device-tensor path does)
@@ -134,6 +138,7 @@ def main():
             dist.all_reduce(xbuf)
         tr("all-reduced")
         api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
+        api.unpack_shared_rhs(dshared_rhs.data_ptr(), drhs.data_ptr(), stream)
         tr("unpacked")
 
     def step():
@@ -316,8 +321,8 @@ def main():
                                 "residual evaluateError leaves in _e is written although the block solver never reads it)",
                            step_without_e_ms=round(dt_noe / args.steps * 1e3, 4),
                            two_call_evaluate_then_build_ms=round(dt_two / args.steps * 1e3, 4),
-                           setup_s=round(t_setup, 2), shared_values=n_shared, ranks_seen=ranks_seen,
-                           sharding="time windows, global pattern; one RCCL all-reduce of [shared Cx entries | rhs | J] per step" if world > 1 else "none"),
+                           setup_s=round(t_setup, 2), shared_values=n_shared, shared_rhs_values=n_shared_rhs, ranks_seen=ranks_seen,
+                           sharding="time windows, global pattern; one RCCL all-reduce of [shared Cx entries | shared rhs entries | J] per step" if world > 1 else "none"),
                roofline=roofline)
 
     if args.solve and rank == 0 and world == 1:

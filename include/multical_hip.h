@@ -172,12 +172,20 @@ int mc_shard_info(const mc_context* ctx, int* rank, int* world);
  * the coefficient band at the window boundaries and the blocks between global design variables (a few 10^5 values,
  * against 10^7..10^8 in the whole array).  After mc_finalize: their count, their (sorted) indices into Cx -- identical
  * on every rank --, and gather / scatter between a device Cx array and a compact device buffer, enqueued on `stream`:
- * pack -> all-reduce(buffer) -> unpack.  Every other entry of Cx is non-zero on exactly one rank (its owner); rhs and J
- * are summed whole.  No counterpart in the reference. */
+ * pack -> all-reduce(buffer) -> unpack.  Every other entry of Cx is non-zero on exactly one rank (its owner).  No
+ * counterpart in the reference. */
 int mc_shared_count(const mc_context* ctx);
 int mc_get_shared_indices(const mc_context* ctx, int* out);
 int mc_pack_shared(mc_context* ctx, const double* d_Cx, double* d_buf, void* stream);
 int mc_unpack_shared(mc_context* ctx, const double* d_buf, double* d_Cx, void* stream);
+/* The same for rhs: the scalar columns more than one rank writes (calibration parameters, coefficients at the window
+ * boundaries; sorted, identical on every rank) and gather / scatter between a device rhs array and a compact buffer.  With
+ * them one all-reduce of [shared Cx entries | shared rhs entries | J] per iteration sums what needs summing; every other
+ * entry of rhs is complete on the rank that owns its window and zero elsewhere. */
+int mc_shared_rhs_count(const mc_context* ctx);
+int mc_get_shared_rhs_indices(const mc_context* ctx, int* out);
+int mc_pack_shared_rhs(mc_context* ctx, const double* d_rhs, double* d_buf, void* stream);
+int mc_unpack_shared_rhs(mc_context* ctx, const double* d_buf, double* d_rhs, void* stream);
 
 /* LinearSystemSolver::initMatrixStructure + BlockCholeskyLinearSystemSolver::initMatrixStructureImplementation
  * (LinearSystemSolver.cpp:117-138, BlockCholeskyLinearSystemSolver.cpp:34-55) plus the symbolic part of

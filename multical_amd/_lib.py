@@ -72,6 +72,10 @@ SIGNATURES = {
     "mc_get_shared_indices": (C.c_int, [_ctx, _ip]),
     "mc_pack_shared": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mc_unpack_shared": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mc_shared_rhs_count": (C.c_int, [_ctx]),
+    "mc_get_shared_rhs_indices": (C.c_int, [_ctx, _ip]),
+    "mc_pack_shared_rhs": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mc_unpack_shared_rhs": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mc_num_launches": (C.c_int, [_ctx]),
     "mc_launch_info": (C.c_int, [_ctx, C.c_int, _ip, _ip, _ip]),
     "mc_launch_counts": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),

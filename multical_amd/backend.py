@@ -366,6 +366,19 @@ class HipApi(object):
     def unpack_shared(self, d_buf, d_cx, stream=None):
         self._chk(self.lib.mc_unpack_shared(self.ctx, C.c_void_p(d_buf), C.c_void_p(d_cx), C.c_void_p(stream or 0)))
 
+    def shared_rhs_indices(self):
+        n = self.lib.mc_shared_rhs_count(self.ctx)
+        out = np.zeros(max(n, 0), np.int32)
+        if n > 0:
+            self._chk(self.lib.mc_get_shared_rhs_indices(self.ctx, out.ctypes.data_as(C.POINTER(C.c_int))))
+        return out
+
+    def pack_shared_rhs(self, d_rhs, d_buf, stream=None):
+        self._chk(self.lib.mc_pack_shared_rhs(self.ctx, C.c_void_p(d_rhs), C.c_void_p(d_buf), C.c_void_p(stream or 0)))
+
+    def unpack_shared_rhs(self, d_buf, d_rhs, stream=None):
+        self._chk(self.lib.mc_unpack_shared_rhs(self.ctx, C.c_void_p(d_buf), C.c_void_p(d_rhs), C.c_void_p(stream or 0)))
+
     LAUNCH_NAMES = ("k_reproj", "k_static", "k_stream<Imu>", "k_stream<Lidar>", "k_motion", "k_stream<ImuSm>",
                     "k_small<GyroPrior>", "k_small<Transformation>")
 

@@ -213,6 +213,9 @@ struct Problem {
   // halos of the coefficient band and the blocks between global design variables.  Only these need the all-reduce;
   // every other entry is written by exactly one rank.  Empty for world == 1.
   std::vector<int> shared_idx;
+  // ... and the scalar columns of rhs that more than one rank writes (the blocks whose diagonal pair is shared): the
+  // calibration parameters and the coefficients at the window boundaries.  Every other entry of rhs is complete on one rank.
+  std::vector<int> shared_rhs;
 
   // ------------------------------------------------------------------ description
   int addDv(int kind, const double* params, int n, int active, double scaling) {
@@ -1007,6 +1010,7 @@ inline void Problem::finalize() {
   lap("footprint tables");
   // ---- shared entries (world > 1): owner rank of every block pair over ALL ranks' work items
   shared_idx.clear();
+  shared_rhs.clear();
   if (world > 1) {
     auto ownerOf = [&](double t) { return shardOf(t); };   // shard_cuts hold every rank's window
     std::vector<signed char> owner(pat_rows.size(), -1);   // -1 untouched, -2 shared, else rank
@@ -1054,6 +1058,7 @@ inline void Problem::finalize() {
       for (int k = pat_colptr[cb]; k < pat_colptr[cb + 1]; ++k) {
         if (owner[k] != -2) continue;
         int rb = pat_rows[k], h = col_h[cb];
+        if (rb == cb) for (int sc = 0; sc < block_dim[cb]; ++sc) shared_rhs.push_back(block_col[cb] + sc);
         for (int sc = 0; sc < block_dim[cb]; ++sc) {
           int base = pat_cp0[cb] + sc * h + (sc * (sc + 1)) / 2 + pat_roff[k];
           int n = (rb == cb) ? sc + 1 : block_dim[rb];

@@ -2414,7 +2414,7 @@ struct mc_context {
   std::string err;
   int device = 0;
   DevBuf<double> x, x_prev, knots, basis, Cx, rhs, e, chi2, Jpart, Jpart2, J, dx;
-  DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab, shared_idx;
+  DevBuf<int> fp_data, fp_off, col_h, status, ofp_data, ofp_off, pat_colptr, pat_rows, pat_roff, pat_cp0, chunk_tab, shared_idx, shared_rhs;
   DevBuf<int> gcb, rep_idx, rep_addr, rep_rhs_col;
   DevBuf<double> rep;   // REP_COPIES x (triangle + rep_cols): matrix replicas, then rhs replicas
   int rep_stride = 0;
@@ -2705,6 +2705,7 @@ void mc_context::uploadStructure() {
   pat_colptr.upload(P.pat_colptr); pat_rows.upload(P.pat_rows); pat_roff.upload(P.pat_roff); pat_cp0.upload(P.pat_cp0);
   chunk_tab.upload(P.chunk_tab);
   shared_idx.upload(P.shared_idx);
+  shared_rhs.upload(P.shared_rhs);
   status.alloc(1);
   Cx.alloc(P.nnz); rhs.alloc(P.j_cols); e.alloc(P.j_rows); chi2.alloc(P.n_terms); J.alloc(1); dx.alloc(P.j_cols);
   std::vector<UpdRec> ur;
@@ -3514,6 +3515,32 @@ int mc_unpack_shared(mc_context* ctx, const double* d_buf, double* d_Cx, void* s
   if (n == 0) return 0;
   HIP_CHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->shared_idx.p, n, d_buf, d_Cx);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_shared_rhs_count(const mc_context* ctx) { return ctx->P.finalized ? (int)ctx->P.shared_rhs.size() : -1; }
+int mc_get_shared_rhs_indices(const mc_context* ctx, int* out) {
+  if (!ctx->P.finalized) return -1;
+  std::memcpy(out, ctx->P.shared_rhs.data(), sizeof(int) * ctx->P.shared_rhs.size());
+  return 0;
+}
+int mc_pack_shared_rhs(mc_context* ctx, const double* d_rhs, double* d_buf, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  int n = (int)ctx->P.shared_rhs.size();
+  if (n == 0) return 0;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->shared_rhs.p, n, d_rhs, d_buf);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+  MC_CATCH(ctx, -1)
+}
+int mc_unpack_shared_rhs(mc_context* ctx, const double* d_buf, double* d_rhs, void* stream) {
+  MC_TRY MC_NEED_FINAL(ctx);
+  int n = (int)ctx->P.shared_rhs.size();
+  if (n == 0) return 0;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->shared_rhs.p, n, d_buf, d_rhs);
   HIP_CHECK(hipGetLastError());
   return 0;
   MC_CATCH(ctx, -1)

@@ -188,6 +188,12 @@ int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {
   return 0;
 }
 int probe_shared_count(void* h) { return (int)((Probe*)h)->P.shared_idx.size(); }
+int probe_shared_rhs_count(void* h) { return (int)((Probe*)h)->P.shared_rhs.size(); }
+int probe_shared_rhs_indices(void* h, int* out) {
+  Problem& P = ((Probe*)h)->P;
+  std::memcpy(out, P.shared_rhs.data(), sizeof(int) * P.shared_rhs.size());
+  return 0;
+}
 int probe_shared_indices(void* h, int* out) {
   Problem& P = ((Probe*)h)->P;
   std::memcpy(out, P.shared_idx.data(), sizeof(int) * P.shared_idx.size());

@@ -204,6 +204,13 @@ class ProbeApi(object):
             self.L.probe_shared_indices(self.h, _i(out))
         return out
 
+    def shared_rhs_indices(self):
+        n = self.L.probe_shared_rhs_count(self.h)
+        out = np.zeros(n, np.int32)
+        if n:
+            self.L.probe_shared_rhs_indices(self.h, _i(out))
+        return out
+
     def my_terms(self):
         f = np.zeros(self.n_terms, np.int32)
         self.L.probe_my_terms(self.h, _i(f))

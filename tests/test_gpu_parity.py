@@ -158,16 +158,27 @@ def test_shared_entries_are_all_that_needs_reducing(small_problem, hip_small):
     assert all(np.array_equal(sidx, p.shared_indices()) for p in parts)
     assert 0 < sidx.size < 0.6 * g.nnz
     st = torch.cuda.current_stream().cuda_stream
+    ridx = parts[0].shared_rhs_indices()
+    assert all(np.array_equal(ridx, p.shared_rhs_indices()) for p in parts) and 0 < ridx.size < g.j_cols
     d = [torch.zeros(g.nnz, dtype=torch.float64, device="cuda:0") for _ in parts]
-    drhs = torch.zeros(g.j_cols, dtype=torch.float64, device="cuda:0")
+    dr = [torch.zeros(g.j_cols, dtype=torch.float64, device="cuda:0") for _ in parts]
     bufs = [torch.zeros(sidx.size, dtype=torch.float64, device="cuda:0") for _ in parts]
-    for p, dc, b in zip(parts, d, bufs):
+    rbufs = [torch.zeros(ridx.size, dtype=torch.float64, device="cuda:0") for _ in parts]
+    for p, dc, drhs, b, rb in zip(parts, d, dr, bufs, rbufs):
         p.build_system_device(True, dc.data_ptr(), drhs.data_ptr(), st)
         p.pack_shared(dc.data_ptr(), b.data_ptr(), st)
-    total = sum(bufs)                       # the all-reduce
-    for p, dc in zip(parts, d):
+        p.pack_shared_rhs(drhs.data_ptr(), rb.data_ptr(), st)
+    total, rtotal = sum(bufs), sum(rbufs)   # the all-reduce
+    for p, dc, drhs in zip(parts, d, dr):
         p.unpack_shared(total.data_ptr(), dc.data_ptr(), st)
+        p.unpack_shared_rhs(rtotal.data_ptr(), drhs.data_ptr(), st)
     torch.cuda.synchronize()
+    # rhs: outside the shared columns one writer, owner values + reduced shared values = the unsharded right-hand side
+    hr = [x.cpu().numpy() for x in dr]
+    private_r = np.ones(g.j_cols, bool)
+    private_r[ridx] = False
+    assert sum(((x != 0.0) & private_r).astype(int) for x in hr).max() <= 1
+    _close(np.where(private_r, sum(np.where(private_r, x, 0.0) for x in hr), hr[0]), rhs, 1e-12)
     h = [x.cpu().numpy() for x in d]
     private = np.ones(g.nnz, bool)
     private[sidx] = False

@@ -103,6 +103,8 @@ def test_motion_terms_are_split_over_the_shards_by_coefficient(small_problem):
         Cx += Cxr
         rhs += rhsr
         writers += Cxr != 0.0
+        rhs_writers = (rhs_writers if r else 0) + (rhsr != 0.0)
+        srhs = p.shared_rhs_indices()
         s = p.shared_indices()
         assert shared is None or np.array_equal(shared, s)      # the same list on every rank
         shared = s
@@ -113,3 +115,7 @@ def test_motion_terms_are_split_over_the_shards_by_coefficient(small_problem):
     private[shared] = False
     assert writers[private].max() <= 1
     assert shared.size < 0.2 * Cx0.size, (shared.size, Cx0.size)
+    # the same for rhs: outside the shared columns (calibration parameters, window boundaries) an entry has one writer
+    private_rhs = np.ones(rhs0.size, bool)
+    private_rhs[srhs] = False
+    assert 0 < srhs.size < 0.5 * rhs0.size and rhs_writers[private_rhs].max() <= 1
