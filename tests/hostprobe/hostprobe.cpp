@@ -176,6 +176,48 @@ int probe_schur_solve(void* h, const double* Cx_plan, const double* Cx, const do
   return 0;
   PR_CATCH(pr, -1)
 }
+// Timing aid (scripts/schur_host_profile.py): the host factorisation of the reduced system alone, as SchurSolver runs it
+// after the device stage -- here behind the reference executor.  out = {factorize best ms, solve best ms, reduced columns}.
+int probe_schur_reduced_bench(void* h, const double* Cx, const double* g, double shift, int parts, int threads, int reps, double* out) {
+  Probe* pr = (Probe*)h;
+  PR_TRY
+  Problem& P = pr->P;
+  std::vector<int> base(P.n_blocks + 1, 0);
+  for (int b = 0; b < P.n_blocks; ++b) base[b + 1] = base[b] + P.block_dim[b];
+  const std::vector<int> sp = blockSplines(P);
+  multical_amd::SchurPlan plan;
+  plan.build(P.j_cols, P.Cp.data(), P.Ci.data(), P.n_blocks, base.data(), sp.data(), Cx, parts);
+  if (!plan.ok) { pr->err = plan.why; return 3; }
+  std::vector<double> S, bS;
+  multical_amd::SchurPlan::HostWork wk;
+  if (!plan.eliminate(Cx, g, shift, S, bS, wk)) return 2;
+  std::vector<int> CpR, CiR;
+  plan.R.toScalar(CpR, CiR);
+  multical_amd::BlockSparseCholesky chol;
+  chol.analyze(plan.R.n, CpR.data(), CiR.data(), plan.R.nb, plan.R.base.data());
+  std::vector<double> when(P.n_blocks), whenR(plan.R.nb);
+  probe_get_block_times(h, when.data());
+  for (int i = 0; i < plan.R.nb; ++i) whenR[i] = when[plan.rblocks[i]];
+  chol.setBlockCoordinates(whenR.data(), threads);
+  std::vector<double> xR(plan.R.n);
+  double bf = 1e30, bs = 1e30;
+  for (int r = 0; r < reps; ++r) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!chol.factorize(S.data())) return 1;
+    const auto t1 = std::chrono::steady_clock::now();
+    chol.solve(bS.data(), xR.data());
+    const auto t2 = std::chrono::steady_clock::now();
+    bf = std::min(bf, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    bs = std::min(bs, std::chrono::duration<double, std::milli>(t2 - t1).count());
+  }
+  out[0] = bf; out[1] = bs; out[2] = plan.R.n;
+  double chk = 0.0;
+  for (double v : xR) chk += v * v;
+  out[3] = chk;
+  std::fprintf(stderr, "reduced factor: %lld entries, %.1f Mflop, %d panels, %d parts, %d top blocks\n", chol.stats().nnz_factor, chol.stats().flops * 1e-6, chol.stats().n_panels, chol.stats().n_parts, chol.stats().n_top_blocks);
+  return 0;
+  PR_CATCH(pr, -1)
+}
 // number of groups kept by this rank / total (sharding checks)
 int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {
   Problem& P = ((Probe*)h)->P;
