@@ -101,6 +101,10 @@ def main():
         api.set_shard(rank, world)
     spec.emit(api)
     api.finalize()
+    if world > 1:
+        # dCx / dE below start out zero and only mc_unpack_shared touches them between passes: a pass may clear just the
+        # values this rank writes (the whole global Cx is 157 MB x world)
+        api.set_clear_mode(True)
     t_setup = time.time() - t0
     note("set-up done in %.1f s, %d terms, nnz %d" % (t_setup, api.n_terms, api.nnz))
     ranks_seen = None
@@ -322,7 +326,7 @@ def main():
                            step_without_e_ms=round(dt_noe / args.steps * 1e3, 4),
                            two_call_evaluate_then_build_ms=round(dt_two / args.steps * 1e3, 4),
                            setup_s=round(t_setup, 2), shared_values=n_shared, shared_rhs_values=n_shared_rhs, ranks_seen=ranks_seen,
-                           sharding="time windows, global pattern; one RCCL all-reduce of [shared Cx entries | shared rhs entries | J] per step" if world > 1 else "none"),
+                           sharding="time windows, global pattern; one RCCL all-reduce of [shared Cx entries | shared rhs entries | J] per step; a pass clears only the values its rank writes (mc_set_clear_mode)" if world > 1 else "none"),
                roofline=roofline)
 
     if args.solve and rank == 0 and world == 1:

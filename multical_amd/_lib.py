@@ -47,6 +47,7 @@ SIGNATURES = {
     "mc_compute_matrix_sqrt": (C.c_int, [C.c_int, _dp, _dp]),
     "mc_set_shard": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "mc_shard_info": (C.c_int, [_ctx, _ip, _ip]),
+    "mc_set_clear_mode": (C.c_int, [_ctx, C.c_int]),
     "mc_finalize": (C.c_int, [_ctx]),
     "mc_dims": (C.c_int, [_ctx, _ip, _ip, _ip, _ip, _ip]),
     "mc_dv_block": (C.c_int, [_ctx, C.c_int, _ip, _ip]),

@@ -182,6 +182,11 @@ class HipApi(object):
     def set_shard(self, rank, world):
         self._chk(self.lib.mc_set_shard(self.ctx, rank, world))
 
+    def set_clear_mode(self, written_only):
+        """With shards: later passes clear only the values this rank writes (mc_set_clear_mode; the caller keeps the rest
+        of every buffer it passes at zero)."""
+        self._chk(self.lib.mc_set_clear_mode(self.ctx, int(bool(written_only))))
+
     # ---- structure
     def finalize(self):
         self._chk(self.lib.mc_finalize(self.ctx))

@@ -216,6 +216,9 @@ struct Problem {
   // ... and the scalar columns of rhs that more than one rank writes (the blocks whose diagonal pair is shared): the
   // calibration parameters and the coefficients at the window boundaries.  Every other entry of rhs is complete on one rank.
   std::vector<int> shared_rhs;
+  // world > 1: what this rank's launches write, as merged ascending (first, count) runs -- of Cx values, of residual rows.
+  // A caller that keeps everything else zero may have the builds clear only these (mc_set_clear_mode).
+  std::vector<std::pair<long long, long long>> written_cx, written_e;
 
   // ------------------------------------------------------------------ description
   int addDv(int kind, const double* params, int n, int active, double scaling) {
@@ -1014,12 +1017,14 @@ inline void Problem::finalize() {
   if (world > 1) {
     auto ownerOf = [&](double t) { return shardOf(t); };   // shard_cuts hold every rank's window
     std::vector<signed char> owner(pat_rows.size(), -1);   // -1 untouched, -2 shared, else rank
+    std::vector<char> mine(pat_rows.size(), 0);            // this rank is among the writers
     auto mark = [&](int b1, int b2, int r) {
       int rb = std::min(b1, b2), cb = std::max(b1, b2);
       const std::vector<int>& rows = col_rows[cb];
       auto it = std::lower_bound(rows.begin(), rows.end(), rb);
       if (it == rows.end() || *it != rb) return;
       size_t k = pat_colptr[cb] + (it - rows.begin());
+      if (r == rank) mine[k] = 1;
       if (owner[k] == -1) owner[k] = (signed char)r;
       else if (owner[k] != r) owner[k] = -2;
     };
@@ -1066,6 +1071,34 @@ inline void Problem::finalize() {
         }
       }
     std::sort(shared_idx.begin(), shared_idx.end());
+    // the values this rank writes, in value order (column block, scalar column, row block)
+    written_cx.clear();
+    auto run = [](std::vector<std::pair<long long, long long>>& v, long long first, long long count) {
+      if (!v.empty() && v.back().first + v.back().second == first) v.back().second += count;
+      else v.push_back({first, count});
+    };
+    for (int cb = 0; cb < n_blocks; ++cb) {
+      bool any = false;
+      for (int k = pat_colptr[cb]; k < pat_colptr[cb + 1] && !any; ++k) any = mine[k] != 0;
+      if (!any) continue;
+      const int h = col_h[cb];
+      for (int sc = 0; sc < block_dim[cb]; ++sc)
+        for (int k = pat_colptr[cb]; k < pat_colptr[cb + 1]; ++k) {
+          if (!mine[k]) continue;
+          const int rb = pat_rows[k];
+          run(written_cx, (long long)pat_cp0[cb] + (long long)sc * h + (sc * (sc + 1)) / 2 + pat_roff[k], (rb == cb) ? sc + 1 : block_dim[rb]);
+        }
+    }
+    // ... and the residual rows of its terms
+    written_e.clear();
+    for (const Batch& b : batches) {
+      if (b.kind == KIND_MOTION) { run(written_e, b.row_base, (long long)b.n_terms * b.dim); continue; }
+      std::vector<int> idx;
+      for (const GroupRec& g : b.my_groups) for (int k = 0; k < g.term_count; ++k) idx.push_back(g.term_first + k);
+      for (const ChunkRec& c : b.my_chunks) for (int k = 0; k < c.term_count; ++k) idx.push_back(b.order[c.term_first + k]);
+      std::sort(idx.begin(), idx.end());
+      for (int i : idx) run(written_e, (long long)b.row_base + (long long)i * b.dim, b.dim);
+    }
   }
   lap("shared entries");
   // ---- J^T (SparseCholesky backend) layout: elements per column and first value index of every term

@@ -50,9 +50,12 @@ def main():
     dshared = torch.zeros(max(1, n_shared), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        api.evaluate_error_device(True, dJ.data_ptr(), None, stream)
-        api.build_system_device(True, dCx.data_ptr(), drhs.data_ptr(), stream)
+    dE = torch.zeros(api.j_rows, dtype=torch.float64, device=dev)
+    if os.environ.get("MC_REHEARSE_FULL_CLEAR") != "1":
+        api.set_clear_mode(True)
+
+    def step():     # bench.py's step without the all-reduce
+        api.evaluate_error_and_build_system_device(True, dJ.data_ptr(), dE.data_ptr(), dCx.data_ptr(), drhs.data_ptr(), stream)
         api.pack_shared(dCx.data_ptr(), dshared.data_ptr(), stream)
         api.unpack_shared(dshared.data_ptr(), dCx.data_ptr(), stream)
 

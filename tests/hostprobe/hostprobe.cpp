@@ -229,6 +229,18 @@ int probe_group_counts(void* h, int* mine, int* total, int* my_terms) {
   }
   return 0;
 }
+// (first, count) runs of the values / residual rows this rank writes (Problem::written_cx / written_e)
+int probe_written_counts(void* h, int* n_cx, int* n_e) {
+  Problem& P = ((Probe*)h)->P;
+  *n_cx = (int)P.written_cx.size(); *n_e = (int)P.written_e.size();
+  return 0;
+}
+int probe_written(void* h, long long* cx, long long* e) {
+  Problem& P = ((Probe*)h)->P;
+  for (size_t i = 0; i < P.written_cx.size(); ++i) { cx[2 * i] = P.written_cx[i].first; cx[2 * i + 1] = P.written_cx[i].second; }
+  for (size_t i = 0; i < P.written_e.size(); ++i) { e[2 * i] = P.written_e[i].first; e[2 * i + 1] = P.written_e[i].second; }
+  return 0;
+}
 int probe_shared_count(void* h) { return (int)((Probe*)h)->P.shared_idx.size(); }
 int probe_shared_rhs_count(void* h) { return (int)((Probe*)h)->P.shared_rhs.size(); }
 int probe_shared_rhs_indices(void* h, int* out) {

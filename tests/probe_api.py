@@ -204,6 +204,15 @@ class ProbeApi(object):
             self.L.probe_shared_indices(self.h, _i(out))
         return out
 
+    def written_runs(self):
+        """(first, count) runs of the Cx values and of the residual rows this rank's launches write."""
+        a, b = C.c_int(), C.c_int()
+        self.L.probe_written_counts(self.h, C.byref(a), C.byref(b))
+        cx = np.zeros((max(1, a.value), 2), np.int64)
+        e = np.zeros((max(1, b.value), 2), np.int64)
+        self.L.probe_written(self.h, cx.ctypes.data_as(C.POINTER(C.c_longlong)), e.ctypes.data_as(C.POINTER(C.c_longlong)))
+        return cx[:a.value], e[:b.value]
+
     def shared_rhs_indices(self):
         n = self.L.probe_shared_rhs_count(self.h)
         out = np.zeros(n, np.int32)

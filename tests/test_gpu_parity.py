@@ -190,6 +190,38 @@ def test_shared_entries_are_all_that_needs_reducing(small_problem, hip_small):
         assert np.array_equal(x[sidx], h[0][sidx])
 
 
+def test_written_only_clear_mode(small_problem):
+    """mc_set_clear_mode(1): a sharded context clears only what its launches write.  Passes into buffers that start out
+    zero -- the second after a state update, so stale values would show -- give what the default mode gives into buffers
+    full of rubbish, and everything outside the rank's runs is never touched."""
+    import torch
+    world = 3
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(5)
+    for r in range(world):
+        a = _hip(small_problem["spec"], r, world)[0]
+        b = _hip(small_problem["spec"], r, world)[0]
+        b.set_clear_mode(True)
+        dx = 1e-3 * rng.standard_normal(a.j_cols)
+        ref = [torch.full((n,), 7.0, dtype=torch.float64, device="cuda:0") for n in (a.nnz, a.j_cols, a.j_rows)]
+        out = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for n in (a.nnz, a.j_cols, a.j_rows)]
+        Ja, Jb = (torch.zeros(1, dtype=torch.float64, device="cuda:0") for _ in range(2))
+        for step in range(3):
+            a.evaluate_error_and_build_system_device(True, Ja.data_ptr(), ref[2].data_ptr(), ref[0].data_ptr(), ref[1].data_ptr(), st)
+            b.evaluate_error_and_build_system_device(True, Jb.data_ptr(), out[2].data_ptr(), out[0].data_ptr(), out[1].data_ptr(), st)
+            torch.cuda.synchronize()
+            for x, y in zip(ref, out):
+                x, y = x.cpu().numpy(), y.cpu().numpy()
+                assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(x).max()), (r, step)
+            assert abs(Ja.item() - Jb.item()) <= 1e-12 * Ja.item()
+            if step == 0:
+                a.apply_update(dx); b.apply_update(dx)
+            elif step == 1:
+                a.revert_update(); b.revert_update()
+        first = out[0].cpu().numpy()
+        assert (first == 0.0).sum() > 0.2 * a.nnz            # a rank's window is a part of the matrix
+
+
 def test_device_pointer_entry_points(hip_small):
     import torch
     g, _ = hip_small

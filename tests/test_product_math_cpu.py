@@ -104,6 +104,20 @@ def test_motion_terms_are_split_over_the_shards_by_coefficient(small_problem):
         rhs += rhsr
         writers += Cxr != 0.0
         rhs_writers = (rhs_writers if r else 0) + (rhsr != 0.0)
+        # mc_set_clear_mode's table: every value this rank writes lies inside its runs, the runs are ascending and disjoint,
+        # and they are a part of the matrix, not all of it
+        runs, erows = p.written_runs()
+        inside = np.zeros(Cx0.size, bool)
+        for first, count in runs:
+            assert count > 0 and not inside[first:first + count].any()
+            inside[first:first + count] = True
+        assert (np.diff(runs[:, 0]) > 0).all() and not (Cxr != 0.0)[~inside].any()
+        assert inside.sum() < 0.75 * Cx0.size, (r, inside.sum(), Cx0.size)
+        rows_in = np.zeros(p.j_rows, bool)
+        for first, count in erows:
+            rows_in[first:first + count] = True
+        assert rows_in.sum() < p.j_rows
+        written_rows = (written_rows if r else 0) + rows_in
         srhs = p.shared_rhs_indices()
         s = p.shared_indices()
         assert shared is None or np.array_equal(shared, s)      # the same list on every rank
@@ -111,6 +125,7 @@ def test_motion_terms_are_split_over_the_shards_by_coefficient(small_problem):
     assert abs(J - J0) <= 1e-12 * J0
     assert np.abs(Cx - Cx0).max() <= 1e-12 * np.abs(Cx0).max()
     assert np.abs(rhs - rhs0).max() <= 1e-12 * np.abs(rhs0).max()
+    assert (written_rows >= 1).all()         # every residual row is in some rank's runs
     private = np.ones(Cx0.size, bool)
     private[shared] = False
     assert writers[private].max() <= 1
