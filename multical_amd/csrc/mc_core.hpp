@@ -127,7 +127,7 @@ struct Batch {
 //   then n x (block index, dim, local column start, global column base)
 enum { OFP_HDR = 4 + MC_MAX_ROLES };
 // chunking limits: terms per chunk (rows must fit the LDS tile) and the target coefficient window
-enum { CHUNK_TERMS_LIDAR = 160, CHUNK_TERMS_IMU = 40, CHUNK_TERMS_IMU_COMPACT = 50, CHUNK_WINDOW = 40, CHUNK_BIAS_WINDOW = 8 };  // terms: two workgroups per CU by LDS (the kernels sit at 2 waves/SIMD by registers anyway); measured 128->160: -6 %, 32->40: -3 %, 48: 1 workgroup per CU, +40 %
+enum { CHUNK_TERMS_LIDAR = 160, CHUNK_TERMS_IMU = 40, CHUNK_TERMS_IMU_COMPACT = 50, CHUNK_TERMS_IMU_COMPACT_POSE = 64, CHUNK_WINDOW = 40, CHUNK_BIAS_WINDOW = 8 };  // terms: two workgroups per CU by LDS (the kernels sit at 2 waves/SIMD by registers anyway); measured 128->160: -6 %, 32->40: -3 %, 48: 1 workgroup per CU, +40 %
 
 // footprint layout in the flat int array `fp_data` at fp_off[f]:
 //   [0] nb   [1] C (local columns)   [2] first buffered spline coefficient, [3] number of buffered coefficients (time-offset kinds)
@@ -561,7 +561,9 @@ inline void Problem::finalize() {
       // The row layout is chosen per LAUNCH (uploadStructure: all calibrated-model batches share one k_stream launch, all
       // scale-misalignment batches another): one batch with a general sqrtInvR, or MC_IMU_PLAIN_ROWS, turns the compact
       // layout off for every batch of that launch, so the chunk size follows the launch, not the batch
-      int maxTerms = lidar ? (int)CHUNK_TERMS_LIDAR : imuLaunchCompact(b.kind) ? (int)CHUNK_TERMS_IMU_COMPACT : (int)CHUNK_TERMS_IMU;
+      // calibrated model: compact pose columns as well (98 doubles per term; k_stream's CP)
+      const bool smKind = b.kind == KIND_ACCEL_SM || b.kind == KIND_GYRO_SM;
+      int maxTerms = lidar ? (int)CHUNK_TERMS_LIDAR : imuLaunchCompact(b.kind) ? (smKind ? (int)CHUNK_TERMS_IMU_COMPACT : (int)CHUNK_TERMS_IMU_COMPACT_POSE) : (int)CHUNK_TERMS_IMU;
       if (const char* ov = std::getenv(lidar ? "MC_CHUNK_TERMS_LIDAR" : "MC_CHUNK_TERMS_IMU")) maxTerms = std::max(1, std::min(256, atoi(ov)));   // tuning aid
       // batch-level other roles
       std::vector<std::pair<int, int>> fixedRoles;  // (role, dv)

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include "../../include/multical_hip.h"
 #include "mc_describe.hpp"
 
@@ -1096,7 +1097,8 @@ __device__ __forceinline__ int b_pose_first_col(const ImuBatchView& b) { return 
 //            of each tile, so it ran 2-3x slower than the vector gathers.
 // Compared with one group per footprint this cuts the atomics by the number of terms that share a window.
 struct StreamDims { int maxT, maxNb, maxNob, maxG, ld, maxTab;
-                    int ldc, nbp; };   // compact-bias layout (IMU): row stride, doubles per term behind the rows
+                    int ldc, nbp;      // compact-bias layout (IMU): row stride, doubles per term behind the rows
+                    int ldp; };        // ... with compact pose columns as well (calibrated IMU model): row stride
 template <class View> struct StreamBatch {
   View v;
   const int* order;      // time-sorted term order of the batch
@@ -1128,7 +1130,8 @@ template <> struct StreamTraits<LidarBatchView> {
   // (w_i * B), stored as [B 6 | w 6]
   enum { D = 1, CO = 12, OCC = MC_LIDAR_OCC };
   static __device__ __forceinline__ int biasColumns(const LidarBatchView&, const int*, int& n) { n = 0; return 0; }
-  static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
+  template <bool CP = false>
+  static __device__ __forceinline__ void coef6(const double* row, const double*, int o, double (&v)[6]) {
     const double2* q = reinterpret_cast<const double2*>(row);
     const double2 b01 = q[0], b23 = q[1], b45 = q[2];
     const double w = row[6 + o];
@@ -1136,7 +1139,8 @@ template <> struct StreamTraits<LidarBatchView> {
   }
   // the two 6-vectors of a band tile's row product, x = row[block o], y = row[block o2]: x y^T = (w_o w_o2) B B^T, so B is
   // read once and only x carries the weights (7 multiplies instead of 12, 5 LDS reads instead of 8)
-  static __device__ __forceinline__ void pair6(const double* row, int o, int o2, double (&x)[6], double (&y)[6]) {
+  template <bool CP = false>
+  static __device__ __forceinline__ void pair6(const double* row, const double*, int o, int o2, double (&x)[6], double (&y)[6]) {
     const double2* q = reinterpret_cast<const double2*>(row);
     const double2 b01 = q[0], b23 = q[1], b45 = q[2];
     const double w = row[6 + o] * row[6 + o2];
@@ -1145,10 +1149,10 @@ template <> struct StreamTraits<LidarBatchView> {
     for (int i = 0; i < 6; ++i) x[i] = w * y[i];
   }
   // returns beta0 (>= 0) or -1 after setting *st
-  template <bool CB = false>
+  template <bool CB = false, bool CP = false>
   static __device__ __forceinline__ int eval(const LidarBatchView& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int term_lo, int term_nbuf,
-                                             double* J, int ld, double* e, TermOut& out, int* st) {
+                                             double* J, int ld, double* e, TermOut& out, int* st, int = 0) {
     int rc[MC_MAX_ROLES];
 #pragma unroll
     for (int r = 0; r < MC_MAX_ROLES; ++r) rc[r] = of[4 + r] >= 0 ? CO + of[4 + r] : -1;
@@ -1171,14 +1175,15 @@ template <> struct StreamTraits<LidarBatchView> {
 // live-window bookkeeping and the compact bias columns; they differ in the term function only.
 template <class View> struct ImuTermFn;
 template <> struct ImuTermFn<ImuBatchView> {
-  template <bool CB> static __device__ __forceinline__ bool run(const ImuBatchView& b, const double* x, int u, bool useM, bool wantJ,
-                                                                const int* rc, double* J, int ld, double* e, TermOut& out) {
-    return imu_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out);
+  template <bool CB, bool CP> static __device__ __forceinline__ bool run(const ImuBatchView& b, const double* x, int u, bool useM, bool wantJ,
+                                                                         const int* rc, double* J, int ld, double* e, TermOut& out, int wofs) {
+    return imu_term<CB, CP>(b, x, u, useM, wantJ, rc, J, ld, e, out, wofs);
   }
 };
 template <> struct ImuTermFn<ImuSmBatchView> {
-  template <bool CB> static __device__ __forceinline__ bool run(const ImuSmBatchView& b, const double* x, int u, bool useM, bool wantJ,
-                                                                const int* rc, double* J, int ld, double* e, TermOut& out) {
+  template <bool CB, bool CP> static __device__ __forceinline__ bool run(const ImuSmBatchView& b, const double* x, int u, bool useM, bool wantJ,
+                                                                         const int* rc, double* J, int ld, double* e, TermOut& out, int) {
+    static_assert(!CP, "compact pose columns: calibrated model only");
     return imu_sm_term<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out);
   }
 };
@@ -1190,27 +1195,56 @@ template <class View> struct ImuStreamTraits {
     n = (c0 >= 0 && b.S == nullptr) ? (b.bias.order > 0 ? 3 * of[3] : 3) : 0;
     return c0;
   }
-  static __device__ __forceinline__ void coef6(const double* row, int o, double (&v)[6]) {
-    const double2* q = reinterpret_cast<const double2*>(row + 6 * o);   // 16-byte aligned: ld and 6 o are even
-    const double2 a = q[0], b2 = q[1], c = q[2];
-    v[0] = a.x; v[1] = a.y; v[2] = b2.x; v[3] = b2.y; v[4] = c.x; v[5] = c.y;
+  // CP: the row holds [P 3 | Q0 3 | Q1 3 | Q2 3], wts = the term's basis weights [w 6 | wd 6 | wdd 6] (imu_term<CB, CP>)
+  template <bool CP = false>
+  static __device__ __forceinline__ void coef6(const double* row, const double* wts, int o, double (&v)[6]) {
+    if constexpr (CP) {
+      const double2* q = reinterpret_cast<const double2*>(row);          // 16-byte aligned: ld and the term stride are even
+      const double2 a = q[0], b2 = q[1], c = q[2], d = q[3], e2 = q[4], f = q[5];
+      const double w0 = wts[o], w1 = wts[6 + o], w2 = wts[12 + o];
+      v[0] = w2 * a.x; v[1] = w2 * a.y; v[2] = w2 * b2.x;
+      v[3] = w0 * b2.y + w1 * d.x + w2 * e2.y;
+      v[4] = w0 * c.x + w1 * d.y + w2 * f.x;
+      v[5] = w0 * c.y + w1 * e2.x + w2 * f.y;
+    } else {
+      const double2* q = reinterpret_cast<const double2*>(row + 6 * o);   // 16-byte aligned: ld and 6 o are even
+      const double2 a = q[0], b2 = q[1], c = q[2];
+      v[0] = a.x; v[1] = a.y; v[2] = b2.x; v[3] = b2.y; v[4] = c.x; v[5] = c.y;
+    }
   }
-  static __device__ __forceinline__ void pair6(const double* row, int o, int o2, double (&x)[6], double (&y)[6]) {
-    coef6(row, o, x);
-    coef6(row, o2, y);
+  template <bool CP = false>
+  static __device__ __forceinline__ void pair6(const double* row, const double* wts, int o, int o2, double (&x)[6], double (&y)[6]) {
+    if constexpr (CP) {
+      const double2* q = reinterpret_cast<const double2*>(row);
+      const double2 a = q[0], b2 = q[1], c = q[2], d = q[3], e2 = q[4], f = q[5];
+      {
+        const double w0 = wts[o], w1 = wts[6 + o], w2 = wts[12 + o];
+        x[0] = w2 * a.x; x[1] = w2 * a.y; x[2] = w2 * b2.x;
+        x[3] = w0 * b2.y + w1 * d.x + w2 * e2.y; x[4] = w0 * c.x + w1 * d.y + w2 * f.x; x[5] = w0 * c.y + w1 * e2.x + w2 * f.y;
+      }
+      {
+        const double w0 = wts[o2], w1 = wts[6 + o2], w2 = wts[12 + o2];
+        y[0] = w2 * a.x; y[1] = w2 * a.y; y[2] = w2 * b2.x;
+        y[3] = w0 * b2.y + w1 * d.x + w2 * e2.y; y[4] = w0 * c.x + w1 * d.y + w2 * f.x; y[5] = w0 * c.y + w1 * e2.x + w2 * f.y;
+      }
+    } else {
+      coef6<false>(row, wts, o, x);
+      coef6<false>(row, wts, o2, y);
+    }
   }
   // CB: compact bias columns -- the bias columns are not stored in the rows (the columns behind them move down by their
   // number) and the role column of the bias is the index of the first live coefficient in the term's bias-weight array
-  template <bool CB = false>
+  template <bool CB = false, bool CP = false>
   static __device__ __forceinline__ int eval(const View& b, const double* x, int u, bool useM, bool wantJ,
                                              const int* of, int pose_lo, int pose_nb, int, int,
-                                             double* J, int ld, double* e, TermOut& out, int* st) {
+                                             double* J, int ld, double* e, TermOut& out, int* st, int wofs = 0) {
     int rc[MC_MAX_ROLES];
     const int bias_0 = of[4 + IMU_ROLE_BIAS], bias_n = bias_0 >= 0 ? 3 * (b.bias.order > 0 ? of[3] : 1) : 0;
+    constexpr int co = CP ? 12 : (int)CO;
 #pragma unroll
     for (int r = 0; r < MC_MAX_ROLES; ++r) {
       const int c = of[4 + r];
-      rc[r] = c >= 0 ? CO + ((CB && bias_0 >= 0 && c > bias_0) ? c - bias_n : c) : -1;
+      rc[r] = c >= 0 ? co + ((CB && bias_0 >= 0 && c > bias_0) ? c - bias_n : c) : -1;
     }
     const double t = b.t[u];
     if (!(t >= b.pose.t_min && t <= b.pose.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
@@ -1222,7 +1256,7 @@ template <class View> struct ImuStreamTraits {
       if (!(t >= b.bias.t_min && t <= b.bias.t_max)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
       rc[IMU_ROLE_BIAS] += (CB ? 1 : 3) * (spline_segment(b.bias, t) - of[2]);
     }
-    if (!ImuTermFn<View>::template run<CB>(b, x, u, useM, wantJ, rc, J, ld, e, out)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
+    if (!ImuTermFn<View>::template run<CB, CP>(b, x, u, useM, wantJ, rc, J, ld, e, out, wofs)) { *st = STATUS_TIME_OUT_OF_SPLINE; return -1; }
     return beta0;
   }
 };
@@ -1233,7 +1267,9 @@ template <class View, bool BUILD, bool CB = false>
 __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_stream(const StreamBatch<View>* __restrict__ batches, DevCommon dc,
                                                 const ChunkRec* __restrict__ chunks, StreamDims dm, int jpart_base) {
   extern __shared__ double smem[];
-  constexpr int D = StreamTraits<View>::D, CO = StreamTraits<View>::CO;
+  // CP: compact pose columns on top of the compact bias columns (calibrated IMU model; imu_term<CB, CP>)
+  constexpr bool CP = CB && std::is_same<View, ImuBatchView>::value;
+  constexpr int D = StreamTraits<View>::D, CO = CP ? 12 : (int)StreamTraits<View>::CO;
   const int tid = threadIdx.x;
   const ChunkRec ch = chunks[blockIdx.x];
   const View b = batches[ch.batch].v;
@@ -1246,8 +1282,9 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
   // CB (IMU kinds without a general sqrtInvR): the 3 x bias_n bias entries of a term are nbc values (w_i on the diagonal of
   // a 3 x 3 block, the same in the three rows); they are kept once per term behind its rows and the rows hold the other
   // Gs = G - bias_n columns only: 152 instead of 216 doubles per term on the calibration problems
-  const int nb = ch.pose_nb, T = ch.term_count, ld = CB ? dm.ldc : dm.ld;
-  const int TS = D * ld + (CB ? dm.nbp : 0);   // doubles per term
+  const int nb = ch.pose_nb, T = ch.term_count, ld = CP ? dm.ldp : CB ? dm.ldc : dm.ld;
+  const int wofs = D * ld + (CB ? dm.nbp : 0);  // CP: the term's basis weights (3 x 6) sit behind its bias weights
+  const int TS = wofs + (CP ? 18 : 0);          // doubles per term
   int cb_0 = -1, cb_n = 0;                     // first bias column among the footprint's others, their number
   if constexpr (CB) { cb_0 = of[4 + IMU_ROLE_BIAS]; cb_n = cb_0 >= 0 ? 3 * (b.bias.order > 0 ? of[3] : 1) : 0; }
   const int Gs = G - cb_n;                     // other columns stored in a row
@@ -1285,7 +1322,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
     TermOut out;
     int st = 0;
     double* Jrow = rows + (size_t)tid * TS;
-    int b0 = StreamTraits<View>::template eval<CB>(b, dc.x, u, dc.useM != 0, build, of, ch.pose_lo, nb, term_lo[u], term_nbuf[u], Jrow, ld, e, out, &st);
+    int b0 = StreamTraits<View>::template eval<CB, CP>(b, dc.x, u, dc.useM != 0, build, of, ch.pose_lo, nb, term_lo[u], term_nbuf[u], Jrow, ld, e, out, &st, CB ? dm.nbp : 0);
     if (b0 >= 0) {
       Jacc = out.w * out.chi2;
       dc.chi2[b.term_base_global + u] = out.chi2;
@@ -1394,7 +1431,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
 #pragma unroll
           for (int r = 0; r < D; ++r) {
             double xv[6], yv[6];
-            StreamTraits<View>::pair6(px + r * ld, o, o + d, xv, yv);
+            StreamTraits<View>::template pair6<CP>(px + r * ld, px + wofs, o, o + d, xv, yv);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -1451,7 +1488,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
 #pragma unroll
         for (int r = 0; r < D; ++r) {
           double xv[6];
-          StreamTraits<View>::coef6(px + r * ld, o, xv);
+          StreamTraits<View>::template coef6<CP>(px + r * ld, px + wofs, o, xv);
           const double2* qy = reinterpret_cast<const double2*>(px + r * ld + CO + GT * gt);   // columns past G: zeroed padding
           const double2 y01 = qy[0], y23 = qy[1];
           const double yv[GT] = {y01.x, y01.y, y23.x, y23.y};
@@ -1509,7 +1546,7 @@ __global__ __launch_bounds__(256, BUILD ? StreamTraits<View>::OCC : 1) void k_st
 #pragma unroll
             for (int r = 0; r < D; ++r) {
               double xv[6];
-              StreamTraits<View>::coef6(px + r * ld, o, xv);
+              StreamTraits<View>::template coef6<CP>(px + r * ld, px + wofs, o, xv);
 #pragma unroll
               for (int i = 0; i < 6; ++i) acc[i][r] += xv[i] * w;
             }
@@ -2979,8 +3016,10 @@ void mc_context::uploadStructure() {
       const bool cb = l != LAUNCH_LIDAR && L.compact_bias && std::getenv("MC_IMU_PLAIN_ROWS") == nullptr;
       L.compact_bias = cb;
       dm.ldc = 36 + ((L.max_gs + 1 + 3) / 4) * 4;
+      dm.ldp = 12 + ((L.max_gs + 1 + 3) / 4) * 4;
       dm.nbp = (L.max_nbc + 1) & ~1;
-      const size_t term_doubles = cb ? (size_t)dim * dm.ldc + dm.nbp : (size_t)dim * dm.ld;
+      const bool cp = cb && l == LAUNCH_IMU;   // k_stream<ImuBatchView, true, true>: compact pose columns too
+      const size_t term_doubles = cp ? (size_t)dim * dm.ldp + dm.nbp + 18 : cb ? (size_t)dim * dm.ldc + dm.nbp : (size_t)dim * dm.ld;
       size_t ints = (size_t)dm.maxT + 2 * (dm.maxNb + 1) + dm.maxTab + (size_t)dm.maxG * dm.maxNb + 4;
       L.lds_bytes = (int)((size_t)dm.maxT * term_doubles * sizeof(double) + ints * sizeof(int) + 16);
       if (L.lds_bytes > 150 * 1024) throw std::runtime_error("chunk tile exceeds the LDS budget");

@@ -392,9 +392,13 @@ MC_HD void body_rate(const PoseSample& ps, const double* v, double* rate, double
 }
 // CB (stream kernel, no general sqrtInvR): the bias columns of the three rows hold one value per live bias coefficient
 // (w_i on the diagonal of a 3 x 3 block), so it is written once, behind the rows: J[3 ld + rolecol[BIAS] + i]
-template <bool CB = false>
+// CP (stream kernel, with CB): the pose-coefficient columns are rank three in the basis weights -- block i of residual row r is
+// [ wdd_i P_r | w_i Q0_r + wd_i Q1_r + wdd_i Q2_r ] -- and are stored that way: the row keeps [P_r Q0_r Q1_r Q2_r] (12 values,
+// scaled) at rolecol[POSE], and the term keeps w, wd, wdd (3 x 6) once behind its rows at J[3 ld + wofs]: 54 instead of 108
+// doubles per term, which is what lets a chunk hold half as many terms again.
+template <bool CB = false, bool CP = false>
 MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bool wantJ, const int* rolecol, double* J,
-                    int ld, double* e, TermOut& out) {
+                    int ld, double* e, TermOut& out, int wofs = 0) {
   double t = b.t[k];
   PoseSample ps;
   bool ok = b.is_accel ? pose_sample<3>(b.pose, x, t, ps) : pose_sample<2>(b.pose, x, t, ps);
@@ -544,6 +548,18 @@ MC_HD bool imu_term(const ImuBatchView& b, const double* x, int k, bool useM, bo
   }
   if (rolecol[IMU_ROLE_POSE] >= 0) {
     double f = sw * b.pose_scale;
+    if (CP) {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          double* q = J + r * ld + rolecol[IMU_ROLE_POSE] + c;
+          q[0] = f * P[3 * r + c]; q[3] = f * Q0[3 * r + c]; q[6] = f * Q1[3 * r + c]; q[9] = f * Q2[3 * r + c];
+        }
+      for (int i = 0; i < S6; ++i) {
+        J[3 * ld + wofs + i] = ps.w[0][i];
+        J[3 * ld + wofs + S6 + i] = ps.w[1][i];
+        J[3 * ld + wofs + 2 * S6 + i] = b.is_accel ? ps.w[2][i] : 0.0;
+      }
+    } else
     for (int i = 0; i < S6; ++i) {
       double w0 = ps.w[0][i], w1 = ps.w[1][i], w2 = b.is_accel ? ps.w[2][i] : 0.0;
       for (int r = 0; r < 3; ++r)

@@ -139,7 +139,12 @@ def test_bench_workload_itself_against_the_host_build():
     np.maximum.at(rmax, Ci, np.abs(Cxp))
     tol = 1e-8 * np.sqrt(np.maximum(cmax[col_of], 1e-300) * np.maximum(np.maximum(rmax, cmax)[Ci], 1e-300))
     assert np.all(np.abs(Cxg - Cxp) <= tol)
-    assert np.array_equal(Cxg == 0.0, Cxp == 0.0)
+    # structural zeros: the two zero patterns agree.  An entry that is zero by cancellation inside a written block may come out
+    # as 0.0 in one build and as rounding residue in the other (seen: one of 19.6 M entries, 2e-9 against entries of 1e7 in
+    # its row and column, once the IMU rows were stored in rank form): such an entry must be a handful and far below the
+    # entry-wise bar above; anything else is a block one side wrote and the other did not
+    bad = np.flatnonzero((Cxg == 0.0) != (Cxp == 0.0))
+    assert bad.size <= 20 and np.all(np.abs(Cxg[bad] - Cxp[bad]) <= 1e-6 * tol[bad]), (bad.size, bad[:8], Cxg[bad[:8]], Cxp[bad[:8]], Ci[bad[:8]], col_of[bad[:8]])
     # the fused pass (what bench.py's step launches) gives the same system
     import torch
     st = torch.cuda.current_stream().cuda_stream
