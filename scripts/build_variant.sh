@@ -8,4 +8,4 @@ mkdir -p multical_amd/csrc/build
 [ -f multical_amd/csrc/build/mc_host.o ] || g++ -O3 -march=x86-64-v3 -std=c++17 -fPIC -c -o multical_amd/csrc/build/mc_host.o multical_amd/csrc/mc_host.cpp
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Xarch_host -march=x86-64-v3 "$@" -fPIC -c -o multical_amd/csrc/build/mc_kernels_$tag.o multical_amd/csrc/mc_kernels.hip
 [ -f multical_amd/csrc/build/mc_driver.o ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xarch_host -march=x86-64-v3 -fPIC -c -o multical_amd/csrc/build/mc_driver.o multical_amd/csrc/mc_driver.hip
-hipcc -shared -fPIC -o multical_amd/libmulticalhip_$tag.so multical_amd/csrc/build/mc_kernels_$tag.o multical_amd/csrc/build/mc_driver.o multical_amd/csrc/build/mc_host.o
+hipcc -shared -fPIC -o multical_amd/libmulticalhip_$tag.so multical_amd/csrc/build/mc_kernels_$tag.o multical_amd/csrc/build/mc_driver.o multical_amd/csrc/build/mc_host.o multical_amd/csrc/build/mc_schur.o
