@@ -769,7 +769,74 @@ class BlockSparseCholesky {
       for (int cj = 0; cj < DJ; ++cj) P[r + (size_t)cj * ldp] -= s[cj];
     }
   }
+#if defined(__AVX2__) && defined(__FMA__) && defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define MC_CHOLESKY_AVX512 1
+  // The same tile with 512-bit vectors (hosts that have them; chosen once at run time): DJ columns x 8 RV rows in
+  // registers, the tail rows under a mask.
+  template <int DJ, int RV>
+  __attribute__((target("avx512f"))) static void updateTile512(const double* __restrict__ T, int ld, int boff, int src, int len, int dk,
+                                                               double* __restrict__ P, int ldp) {
+    alignas(64) double B[KC][DJ];
+    for (int ck = 0; ck < dk; ++ck)
+      for (int cj = 0; cj < DJ; ++cj) B[ck][cj] = T[boff + cj + (size_t)ck * ld];
+    const double* __restrict__ S = T + src;
+    for (int r = 0; r < len; r += 8 * RV) {
+      __mmask8 m[RV];
+#pragma GCC unroll 4
+      for (int v = 0; v < RV; ++v) {
+        const int left = len - r - 8 * v;
+        m[v] = left >= 8 ? (__mmask8)0xff : left > 0 ? (__mmask8)((1u << left) - 1u) : (__mmask8)0;
+      }
+      __m512d acc[DJ][RV];
+#pragma GCC unroll 6
+      for (int cj = 0; cj < DJ; ++cj)
+#pragma GCC unroll 4
+        for (int v = 0; v < RV; ++v) acc[cj][v] = _mm512_maskz_loadu_pd(m[v], P + r + 8 * v + (size_t)cj * ldp);
+      for (int ck = 0; ck < dk; ++ck) {
+        __m512d a[RV];
+#pragma GCC unroll 4
+        for (int v = 0; v < RV; ++v) a[v] = _mm512_maskz_loadu_pd(m[v], S + r + 8 * v + (size_t)ck * ld);
+#pragma GCC unroll 6
+        for (int cj = 0; cj < DJ; ++cj) {
+          const __m512d bb = _mm512_set1_pd(B[ck][cj]);
+#pragma GCC unroll 4
+          for (int v = 0; v < RV; ++v) acc[cj][v] = _mm512_fnmadd_pd(a[v], bb, acc[cj][v]);
+        }
+      }
+#pragma GCC unroll 6
+      for (int cj = 0; cj < DJ; ++cj)
+#pragma GCC unroll 4
+        for (int v = 0; v < RV; ++v) _mm512_mask_storeu_pd(P + r + 8 * v + (size_t)cj * ldp, m[v], acc[cj][v]);
+    }
+  }
+  static bool wide() {
+    static const bool w = std::getenv("MC_CHOLESKY_NO_AVX512") == nullptr && __builtin_cpu_supports("avx512f");
+    return w;
+  }
+#endif
   static void panelUpdate(const double* T, int ld, int src, int len, int dk, int dj, double* P, int ldp) {
+#ifdef MC_CHOLESKY_AVX512
+    if (wide()) {
+      for (int k0 = 0; k0 < dk; k0 += KC) {
+        const double* Tk = T + (size_t)k0 * ld;
+        const int kc = std::min<int>(KC, dk - k0);
+        for (int j0 = 0; j0 < dj;) {
+          const int c = std::min(6, dj - j0);
+          double* Pj = P + (size_t)j0 * ldp;
+          switch (c) {
+            case 6: updateTile512<6, 3>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+            case 5: updateTile512<5, 3>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+            case 4: updateTile512<4, 4>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+            case 3: updateTile512<3, 4>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+            case 2: updateTile512<2, 4>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+            default: updateTile512<1, 4>(Tk, ld, j0, src, len, kc, Pj, ldp); break;
+          }
+          j0 += c;
+        }
+      }
+      return;
+    }
+#endif
     for (int k0 = 0; k0 < dk; k0 += KC) {
       const double* Tk = T + (size_t)k0 * ld;
       const int kc = std::min<int>(KC, dk - k0);

@@ -6,6 +6,7 @@ aslam_backend/test/LinearSolverTests.cpp:42-57: dx equal to 1e-6); the same is d
 of the shape the hot path produces: block-banded spline part, a border of global blocks every row touches, blocks of
 dimension 6/3/2/1, upper-triangular scalar CCS in fillCCS order."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -287,6 +288,26 @@ def test_linked_update_kernel_is_the_vector_one():
     assert syms, "update kernel not found in " + lib
     dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", "--disassemble=" + syms[0], lib], text=True)
     assert "vfnmadd" in dis and "ymm" in dis
+
+
+def test_both_vector_widths_of_the_update_kernel():
+    """The panel update has a 256-bit and a 512-bit form, chosen once per process from the CPU (MC_CHOLESKY_NO_AVX512
+    forces the narrow one).  Whatever this host picks, the other one is run too: the dense-solve and dissection tests
+    again in a fresh process with the switch set, and the 512-bit tile must be in the library for hosts that have it."""
+    import shutil
+    import subprocess
+    import sys
+    from multical_amd import _lib
+    env = dict(os.environ, MC_CHOLESKY_NO_AVX512="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", __file__, "-k",
+                        "solution_matches_dense or dissection_matches_dense or come_back"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if shutil.which("nm") and shutil.which("objdump"):
+        syms = [l.split()[-1] for l in subprocess.check_output(["nm", _lib.LIB_PATH], text=True).splitlines()
+                if "BlockSparseCholesky13updateTile512ILi6ELi3" in l]
+        assert syms, "512-bit update kernel not found in " + _lib.LIB_PATH
+        dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", "--disassemble=" + syms[0], _lib.LIB_PATH], text=True)
+        assert "vfnmadd" in dis and "zmm" in dis
 
 
 @pytest.mark.parametrize("threads", [1, 3])
