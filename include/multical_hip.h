@@ -172,8 +172,8 @@ int mc_shard_info(const mc_context* ctx, int* rank, int* world);
  * Cx is 1.25 GB, 0.19 ms of a 1.5 ms build.  The caller then owns the rest of the contract: every d_Cx / d_e buffer it
  * passes starts out zero (one hipMemset when it is allocated) and between passes only values this rank writes are
  * changed in it (mc_unpack_shared does exactly that; an all-reduce of the whole array does not).  0 (default): every
- * pass clears everything, any buffer may be passed.  Without shards the call changes nothing.  No counterpart in the
- * reference. */
+ * pass clears everything, any buffer may be passed.  Without shards the call changes nothing.  mc_optimize_sharded sums
+ * whole arrays and therefore switches the mode off on its context.  No counterpart in the reference. */
 int mc_set_clear_mode(mc_context* ctx, int written_only);
 
 /* With shards, only the value entries that more than one rank's terms can write need summing over ranks: the halos of

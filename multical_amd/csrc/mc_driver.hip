@@ -39,6 +39,9 @@ static int optimizeImpl(mc_context* ctx, const mc_optimizer_options* opt, mc_sol
                         "which sums the cost, the normal equations and the step over the ranks");
       hooks.rank = rank; hooks.world = world;
       if (sharded && world > 1 && (!hooks.allreduce || !hooks.broadcast)) throw Exception("mc_optimize_sharded: both callbacks are required");
+      // the minimiser sums the WHOLE Cx over the ranks into its own buffers: the other ranks' values land in them, which
+      // is what mc_set_clear_mode(1) rules out
+      if (sharded && world > 1) mc_set_clear_mode(ctx, 0);
     }
     MinimiserSettings cfg;
     cfg.stepTolerance = opt->convergenceDeltaX;
