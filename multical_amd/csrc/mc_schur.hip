@@ -11,7 +11,7 @@
 //   k_schur_factor   one workgroup per interior: banded Cholesky A_II = U^T U in a circular bw x bw LDS window (right-looking,
 //                    one scalar column per step) and, after every d columns, the block of W = A_BI U^-1 they complete
 //                    (lane = boundary row; the last bw - d columns of W in an LDS ring)
-//   k_schur_syrk     S -= W W^T and b_S -= W y: 64 x 64 output tiles, 16-deep LDS panels, 4 x 4 per lane, fp64 atomics into
+//   k_schur_syrk     S -= W W^T and b_S -= W y: 64 x 64 output tiles, 16-deep LDS panels, fp64 matrix cores (a 32 x 32 quadrant per wave), fp64 atomics into
 //                    the reduced system's value array (neighbouring interiors share separators, all share the calibration blocks)
 //   k_schur_back     x_I = U^-1 (y - W^T x_B): wave-per-column products, then the banded back-substitution by one wave with
 //                    the last bw - 1 unknowns in its lanes
@@ -222,42 +222,51 @@ __global__ __launch_bounds__(FACTOR_THREADS) void k_schur_factor(const PartDev* 
   }
 }
 
-// S -= W W^T (upper triangle, through the part's scatter table), bS -= W y.  grid: (tile pairs, parts)
+// S -= W W^T (upper triangle, through the part's scatter table), bS -= W y.  grid: 8 ceil(parts / 8) tile pairs
 __global__ __launch_bounds__(256) void k_schur_syrk(const PartDev* __restrict__ parts, const double* __restrict__ W,
                                                     const SchurPlan::Scatter* __restrict__ scatter, const int* __restrict__ browBlk,
                                                     const int* __restrict__ browOff, const int* __restrict__ browCol,
-                                                    double* __restrict__ S, double* __restrict__ bS) {
-  const PartDev pt = parts[blockIdx.y];
+                                                    double* __restrict__ S, double* __restrict__ bS, int tilePairs, int nParts) {
+  // workgroup n runs on XCD n % 8 (round-robin dispatch), and every tile pair of a part reads that part's whole W: the
+  // pairs of one part are given to one XCD, so W comes from HBM once and from that XCD's L2 afterwards
+  const int n = blockIdx.x, slot = n >> 3, part = (n & 7) + 8 * (slot / tilePairs);
+  if (part >= nParts) return;
+  const PartDev pt = parts[part];
   const int nW = pt.nB + 1, nT = (nW + 63) >> 6;
-  int tb = 0, rem = blockIdx.x;     // tile pair (ta <= tb), numbered column by column
+  int tb = 0, rem = slot % tilePairs;     // tile pair (ta <= tb), numbered column by column
   while (tb < nT && rem > tb) { rem -= tb + 1; ++tb; }
   if (tb >= nT) return;
   const int ta = rem, a0 = ta << 6, b0 = tb << 6;
-  __shared__ double As[16][65], Bs[16][65];
+  constexpr int KP = 16;     // depth of the LDS panels (32: slower)
+  __shared__ double As[KP][65], Bs[KP][65];
   const double* Wt = W + pt.wOff;
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, ldW = pt.ldW;
-  double acc[4][4];
+  const int tid = threadIdx.x, ldW = pt.ldW;
+  // fp64 matrix cores: each wave owns a 32 x 32 quadrant of the tile as 2 x 2 products of v_mfma_f64_16x16x4 (A[i][k] and
+  // B[k][j] one double per lane, lane = 16 k + i; D: row = (lane >> 4) + 4 reg, column = lane & 15).  Same peak as the vector
+  // unit on this part, but an operand pair feeds 2048 flops where the 4 x 4 register tile re-read 8 LDS values per 32.
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int lane = tid & 63, wv = tid >> 6, wr = (wv >> 1) * 32, wc = (wv & 1) * 32, l16 = lane & 15, lk = lane >> 4;
+  d4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  for (int k0 = 0; k0 < pt.nI; k0 += 16) {
+    for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < pt.nI; k0 += KP) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < KP / 4; ++i) {
       const int e = tid + 256 * i, kk = e >> 6, ai = e & 63, k = k0 + kk;
       As[kk][ai] = (k < pt.nI && a0 + ai < nW) ? Wt[(long long)k * ldW + a0 + ai] : 0.0;
       Bs[kk][ai] = (k < pt.nI && b0 + ai < nW) ? Wt[(long long)k * ldW + b0 + ai] : 0.0;
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    for (int k4 = 0; k4 < KP; k4 += 4) {
+      const double a0v = As[k4 + lk][wr + l16], a1v = As[k4 + lk][wr + 16 + l16];
+      const double b0v = Bs[k4 + lk][wc + l16], b1v = Bs[k4 + lk][wc + 16 + l16];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b0v, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b1v, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b0v, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, acc[1][1], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -266,17 +275,19 @@ __global__ __launch_bounds__(256) void k_schur_syrk(const PartDev* __restrict__ 
   const int* bo = browOff + pt.browBase;
   const int* bc = browCol + pt.browBase;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int a = a0 + ty * 4 + i, b = b0 + tx * 4 + j;
-      if (a > b || b >= nW || a >= pt.nB) continue;
-      const double v = acc[i][j];
-      if (v == 0.0) continue;
-      if (b == pt.nB) { addF64(bS + bc[a], -v); continue; }
-      const SchurPlan::Scatter s = tab[bb[b] * pt.nblk + bb[a]];
-      addF64(S + s.dst + (long long)bo[b] * s.hd + (bo[b] * (bo[b] + 1)) / 2 + bo[a], -v);
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + wr + 16 * i + lk + 4 * r, b = b0 + wc + 16 * j + l16;
+        if (a > b || b >= nW || a >= pt.nB) continue;
+        const double v = acc[i][j][r];
+        if (v == 0.0) continue;
+        if (b == pt.nB) { addF64(bS + bc[a], -v); continue; }
+        const SchurPlan::Scatter s = tab[bb[b] * pt.nblk + bb[a]];
+        addF64(S + s.dst + (long long)bo[b] * s.hd + (bo[b] * (bo[b] + 1)) / 2 + bo[a], -v);
+      }
 }
 
 __global__ __launch_bounds__(256) void k_schur_place(const int* __restrict__ rcol, int nR, const double* __restrict__ xR, double* __restrict__ x) {
@@ -464,7 +475,7 @@ int SchurSolver::solve(const double* d_Cx, const double* d_g, double shift, doub
   lap(0);
   hipLaunchKernelGGL(k_schur_factor, dim3(P), dim3(FACTOR_THREADS), m.factorLds, st, m.parts.p, m.Ab.p, m.W.p, pl.d, pl.bw, m.flag.p);
   lap(1);
-  hipLaunchKernelGGL(k_schur_syrk, dim3(m.maxTilePairs, P), dim3(256), 0, st, m.parts.p, m.W.p, m.scatter.p, m.browBlk.p, m.browOff.p, m.browCol.p, m.S.p, m.bS.p);
+  hipLaunchKernelGGL(k_schur_syrk, dim3(8 * ((P + 7) / 8) * m.maxTilePairs), dim3(256), 0, st, m.parts.p, m.W.p, m.scatter.p, m.browBlk.p, m.browOff.p, m.browCol.p, m.S.p, m.bS.p, m.maxTilePairs, P);
   lap(2);
   int flag[2] = {0, 0};
   hipDo(hipMemcpyAsync(flag, m.flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st), "flag read-back");
